@@ -1,0 +1,40 @@
+"""CPU oracle for the LTX-Video denoise hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This package is a plain-PyTorch (CPU, any float dtype; fp32 = "truth", bf16 = the
+reference's eager rounding points) restatement of the algorithm that the reference
+project (soasme/LTX-Video-GPUPoor) runs on its hot path:
+
+    Transformer3DModel.forward           ltx_video/models/transformers/transformer3d.py:328-507
+    BasicTransformerBlock / Attention    ltx_video/models/transformers/attention.py:205-364, 986-1173
+    pay_attention (sdpa eager branch)    wan/modules/attention.py:99-116, 162-199, 344-347
+    CausalVideoAutoencoder.decode        ltx_video/models/autoencoders/{vae,causal_video_autoencoder,...}.py
+    RectifiedFlowScheduler               ltx_video/schedulers/rf.py
+    guidance math of the denoise loop    ltx_video/pipelines/pipeline_ltx_video.py:1183-1222
+
+Who may import it: ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py``.  The product package (``ltx-video-gpupoor_amd/ltxmi``) must
+never import, call or fall back to anything in here; it fails loudly when the HIP
+library is missing.
+
+Pinning status
+--------------
+* Everything that is the reference's OWN code (the list above) is pinned: the
+  golden vectors in ``tests/golden/*.safetensors`` were produced by importing the
+  reference's modules from /root/reference in the build container
+  (``oracle/gen/make_golden.py``) and ``tests/test_oracle_golden.py`` checks this
+  restatement against them.
+* The leaves the reference takes from the third-party ``diffusers`` package
+  (>=0.31.0, not installed here, not vendored in the reference):
+  ``AdaLayerNormSingle``, ``PixArtAlphaCombinedTimestepSizeEmbeddings``,
+  ``TimestepEmbedding``, ``PixArtAlphaTextProjection``, ``RMSNorm``, ``GELU`` are
+  restated in ``oracle/leaves.py`` from their published definitions.  The
+  reference holds no test or fixture at that boundary, so those few functions
+  are **parity unpinned** (the golden generator had to use the same restatement
+  as a stand-in for the absent package).  The reference's own in-repo duplicate of
+  the sinusoid (``ltx_video/models/transformers/embeddings.py:10-50``) does pin
+  ``get_timestep_embedding``.
+* The guidance math (CFG-star / STG / std-rescale) lives inside
+  ``LTXVideoPipeline.__call__`` which cannot run on CPU (hard-coded
+  ``.to("cuda")`` at pipeline_ltx_video.py:1041) -- it is restated line by line and
+  is **parity unpinned**.
+"""

@@ -1,0 +1,362 @@
+"""Generate the golden vectors in tests/golden/ by running the REFERENCE's own code.
+
+BUILD-CONTAINER-ONLY: imports the reference's modules from /root/reference through
+oracle/gen/ref_shims.py, runs seeded tiny cases on CPU, and stores inputs, weights
+and outputs as plain tensors (.safetensors) plus a JSON manifest.  Only data is
+written -- no reference source, bytecode or pickled objects.
+
+    python -m oracle.gen.make_golden          # from the repo root
+
+Cases: G1 precompute_freqs_cis, G2 apply_rotary_emb, G3 attention
+processor (self / cross+mask / STG values), G4 BasicTransformerBlock (per-batch and
+per-frame timestep), G5 Transformer3DModel.forward (fp32 + bf16 twin), G6 scheduler,
+G8 CausalConv3d, G9 ResnetBlock3D / DepthToSpaceUpsample / PixelNorm / (un)patchify,
+G10 Decoder.forward + decode (plain, z-tiled, hw-tiled) + vae_decode for both
+decoder block plans.
+"""
+import json
+import os
+import sys
+import types
+
+import torch
+from safetensors.torch import save_file
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.gen import ref_shims  # noqa: E402
+
+ref_shims.install()
+
+import ltx_video.models.transformers.transformer3d as ref_t3  # noqa: E402
+import ltx_video.models.transformers.attention as ref_attn  # noqa: E402
+import ltx_video.models.autoencoders.causal_video_autoencoder as ref_cva  # noqa: E402
+import ltx_video.models.autoencoders.causal_conv3d as ref_cc3  # noqa: E402
+import ltx_video.models.autoencoders.pixel_norm as ref_pn  # noqa: E402
+import ltx_video.models.autoencoders.vae_encode as ref_ve  # noqa: E402
+import ltx_video.schedulers.rf as ref_rf  # noqa: E402
+import ltx_video.models.transformers.symmetric_patchifier as ref_sp  # noqa: E402
+from ltx_video.utils.skip_layer_strategy import SkipLayerStrategy  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+MANIFEST = {}
+
+
+def save(name, tensors, meta=None):
+    t = {k: v.detach().clone().contiguous() for k, v in tensors.items()}
+    save_file(t, os.path.join(OUT, name + ".safetensors"))
+    MANIFEST[name] = meta or {}
+    print(f"  {name}: {len(t)} tensors, {sum(v.numel() * v.element_size() for v in t.values()) / 1e6:.2f} MB")
+
+
+TINY_DIT = dict(
+    num_attention_heads=2, attention_head_dim=32, in_channels=16, out_channels=16, num_layers=2,
+    cross_attention_dim=64, caption_channels=32, attention_bias=True, activation_fn="gelu-approximate",
+    norm_elementwise_affine=False, norm_eps=1e-6, qk_norm="rms_norm", standardization_norm="rms_norm",
+    adaptive_norm="single_scale_shift", positional_embedding_type="rope",
+    positional_embedding_theta=10000.0, positional_embedding_max_pos=[20, 2048, 2048],
+    timestep_scale_multiplier=1000,
+)
+
+
+def build_dit(cfg, seed):
+    torch.manual_seed(seed)
+    model = ref_t3.Transformer3DModel(**cfg).eval()
+    # move q/k norm weights off their all-ones init so the weight path is exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("q_norm.weight") or n.endswith("k_norm.weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+    return model
+
+
+def coords(f, h, w, b, fps=25.0):
+    pat = ref_sp.SymmetricPatchifier(patch_size=1)
+    lc = pat.get_latent_coords(f, h, w, b, "cpu")
+    pc = ref_ve.latent_to_pixel_coords_from_factors(lc, (8, 32, 32), causal_fix=True).to(torch.float32)
+    pc[:, 0] = pc[:, 0] * (1.0 / fps)
+    return lc, pc
+
+
+@torch.no_grad()
+def g1_g2():
+    print("G1/G2 rope")
+    t = {}
+    meta = {"cases": []}
+    for tag, (heads, dh, grid) in {"d48": (2, 24, (2, 4, 4)), "d64": (2, 32, (3, 4, 6)),
+                                   "d2048": (32, 64, (2, 2, 3))}.items():
+        cfg = dict(TINY_DIT, num_attention_heads=heads, attention_head_dim=dh, num_layers=1,
+                   cross_attention_dim=heads * dh)
+        model = build_dit(cfg, 0)
+        lc, pc = coords(*grid, 2)
+        cos, sin = model.precompute_freqs_cis(pc)
+        t[f"{tag}.latent_coords"] = lc
+        t[f"{tag}.indices_grid"] = pc
+        t[f"{tag}.cos"], t[f"{tag}.sin"] = cos, sin
+        x = torch.randn(2, pc.shape[-1], heads * dh, generator=torch.Generator().manual_seed(3))
+        t[f"{tag}.x"] = x
+        t[f"{tag}.rot"] = ref_attn.Attention.apply_rotary_emb(x, (cos, sin))
+        meta["cases"].append(dict(tag=tag, heads=heads, dh=dh, grid=grid))
+    save("g1_rope", t, meta)
+
+
+def dit_inputs(cfg, f, h, w, B, T, seed, per_token_timestep=False):
+    g = torch.Generator().manual_seed(seed)
+    N = f * h * w
+    x = torch.randn(B, N, cfg["in_channels"], generator=g)
+    enc = torch.randn(B, T, cfg["caption_channels"], generator=g)
+    mask = torch.ones(B, T)
+    mask[:, T - 3:] = 0
+    mask[0, T - 5:] = 0
+    if per_token_timestep:
+        ts = torch.full((B, N), 0.7)
+        ts[:, : h * w] = 0.0            # first latent frame is hard-conditioned (i2v)
+    else:
+        ts = torch.full((B, 1), 0.7)
+    return x, enc, mask, ts
+
+
+@torch.no_grad()
+def g3_g4_g5():
+    print("G3/G4/G5 DiT")
+    cfg = TINY_DIT
+    f, h, w, B, T = 2, 3, 4, 3, 8
+    model = build_dit(cfg, 10)
+    sd = {k: v for k, v in model.state_dict().items()}
+    _, pc = coords(f, h, w, 1)
+    freqs = model.precompute_freqs_cis(pc)
+    holder = types.SimpleNamespace(_interrupt=False)
+    D = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+
+    # ---- G3: attention processors on the first block
+    blk = model.transformer_blocks[0]
+    g = torch.Generator().manual_seed(20)
+    hs = torch.randn(B, f * h * w, D, generator=g)
+    ctx = torch.randn(B, T, D, generator=g)
+    bias = torch.zeros(B, 1, T)
+    bias[:, :, T - 3:] = -10000.0
+    t3 = {"hs": hs, "ctx": ctx, "bias": bias, "cos": freqs[0], "sin": freqs[1]}
+    t3["self"] = blk.attn1([hs.clone()], freqs_cis=freqs)
+    t3["cross"] = blk.attn2([hs.clone()], freqs_cis=freqs, encoder_hidden_states=ctx, attention_mask=bias)
+    slm = torch.tensor([1.0, 1.0, 0.0])
+    t3["slm"] = slm
+    t3["self_stg_values"] = blk.attn1([hs.clone()], freqs_cis=freqs, skip_layer_mask=slm,
+                                      skip_layer_strategy=SkipLayerStrategy.AttentionValues)
+    t3["self_stg_skip"] = blk.attn1([hs.clone()], freqs_cis=freqs, skip_layer_mask=slm,
+                                    skip_layer_strategy=SkipLayerStrategy.AttentionSkip)
+    one = torch.tensor([0.0])
+    t3["self_stg_values_b1"] = blk.attn1([hs[:1].clone()], freqs_cis=freqs, skip_layer_mask=one,
+                                         skip_layer_strategy=SkipLayerStrategy.AttentionValues)
+    for k, v in sd.items():
+        if k.startswith("transformer_blocks.0."):
+            t3["sd." + k] = v
+    save("g3_attention", t3, dict(cfg=cfg, grid=(f, h, w), B=B, T=T))
+
+    # ---- G4: one block, per-batch and per-frame timestep tables
+    t4 = {"hs": hs, "ctx": ctx, "bias": bias, "cos": freqs[0], "sin": freqs[1]}
+    temb_b = torch.randn(B, 1, 6 * D, generator=g) * 0.5
+    temb_f = torch.randn(B, f, 6 * D, generator=g) * 0.5
+    t4["temb_b"], t4["temb_f"] = temb_b, temb_f
+    t4["out_b"] = blk(hs.clone(), freqs_cis=freqs, encoder_hidden_states=ctx,
+                      encoder_attention_mask=bias, timestep=temb_b)
+    t4["out_f"] = blk(hs.clone(), freqs_cis=freqs, encoder_hidden_states=ctx,
+                      encoder_attention_mask=bias, timestep=temb_f)
+    t4["out_b_stg"] = blk(hs.clone(), freqs_cis=freqs, encoder_hidden_states=ctx,
+                          encoder_attention_mask=bias, timestep=temb_b, skip_layer_mask=slm,
+                          skip_layer_strategy=SkipLayerStrategy.AttentionValues)
+    t4["out_b_tb"] = blk(hs.clone(), freqs_cis=freqs, encoder_hidden_states=ctx,
+                         encoder_attention_mask=bias, timestep=temb_b, skip_layer_mask=slm,
+                         skip_layer_strategy=SkipLayerStrategy.TransformerBlock)
+    for k, v in sd.items():
+        if k.startswith("transformer_blocks.0."):
+            t4["sd." + k] = v
+    save("g4_block", t4, dict(cfg=cfg, grid=(f, h, w), B=B, T=T))
+
+    # ---- G5: whole model
+    t5 = {"indices_grid": pc}
+    x, enc, mask, ts = dit_inputs(cfg, f, h, w, B, T, 30)
+    skip = model.create_skip_layer_mask(1, 3, 2, [1])
+    t5.update({"x": x, "enc": enc, "mask": mask, "ts": ts, "skip_layer_mask": skip})
+    kw = dict(freqs_cis=freqs, encoder_hidden_states=enc, encoder_attention_mask=mask,
+              latent_shape=(f, h, w), ltxv_model=holder, return_dict=False)
+    t5["out"] = model(x.clone(), timestep=ts, **kw)[0]
+    t5["out_stg"] = model(x.clone(), timestep=ts, skip_layer_mask=skip,
+                          skip_layer_strategy=SkipLayerStrategy.AttentionValues, **kw)[0]
+    _, _, _, ts_tok = dit_inputs(cfg, f, h, w, B, T, 30, per_token_timestep=True)
+    t5["ts_tok"] = ts_tok
+    t5["out_tok"] = model(x.clone(), timestep=ts_tok, **kw)[0]
+    for k, v in sd.items():
+        t5["sd." + k] = v
+    # bf16 twin: the reference's eager path in bf16 (weights, activations, tables)
+    mb = build_dit(cfg, 10).to(torch.bfloat16)
+    fb = mb.precompute_freqs_cis(pc)
+    t5["bf16.cos"], t5["bf16.sin"] = fb
+    t5["bf16.out"] = mb(x.to(torch.bfloat16), freqs_cis=fb, encoder_hidden_states=enc.to(torch.bfloat16),
+                        encoder_attention_mask=mask, timestep=ts, latent_shape=(f, h, w),
+                        ltxv_model=holder, return_dict=False)[0]
+    t5["bf16.out_stg"] = mb(x.to(torch.bfloat16), freqs_cis=fb, encoder_hidden_states=enc.to(torch.bfloat16),
+                            encoder_attention_mask=mask, timestep=ts, latent_shape=(f, h, w),
+                            skip_layer_mask=skip.to(torch.bfloat16),
+                            skip_layer_strategy=SkipLayerStrategy.AttentionValues,
+                            ltxv_model=holder, return_dict=False)[0]
+    save("g5_transformer", t5, dict(cfg=cfg, grid=(f, h, w), B=B, T=T, skip_blocks=[1]))
+
+
+@torch.no_grad()
+def g6():
+    print("G6 scheduler")
+    t = {}
+    shapes = {"c1": (1, 128, 2, 8, 8), "c2": (1, 128, 13, 16, 24), "c3": (1, 128, 16, 22, 38),
+              "c5": (1, 128, 33, 23, 40), "small": (1, 128, 2, 3, 4)}
+    for tag, shp in shapes.items():
+        for steps in (2, 8, 40):
+            s = ref_rf.RectifiedFlowScheduler(num_train_timesteps=1000, shifting="SD3",
+                                              base_resolution=None, target_shift_terminal=0.1)
+            s.set_timesteps(steps, samples_shape=torch.Size(shp), device="cpu")
+            t[f"{tag}.steps{steps}"] = s.timesteps
+    s = ref_rf.RectifiedFlowScheduler(num_train_timesteps=1000, shifting="SD3", base_resolution=None,
+                                      target_shift_terminal=0.1)
+    s.set_timesteps(8, samples_shape=torch.Size(shapes["small"]), device="cpu")
+    g = torch.Generator().manual_seed(5)
+    sample = torch.randn(1, 24, 16, generator=g)
+    v = torch.randn(1, 24, 16, generator=g)
+    t["step.timesteps"] = s.timesteps
+    t["step.sample"], t["step.v"] = sample, v
+    t["step.global"] = s.step(v, s.timesteps[2], sample, return_dict=False)[0]
+    tok = s.timesteps[2].expand(1, 24).clone()
+    tok[:, :12] = 0.0
+    tok[:, 12:16] = 0.31
+    t["step.tok_t"] = tok
+    t["step.per_token"] = s.step(v, tok, sample, return_dict=False)[0]
+    save("g6_scheduler", t, dict(shapes={k: list(v) for k, v in shapes.items()}))
+
+
+TINY_VAE_A = {  # OURS_VAE_CONFIG block plan (diffusers_config_mapping.py:106-130), shrunk
+    "_class_name": "CausalVideoAutoencoder", "dims": 3, "in_channels": 3, "out_channels": 3,
+    "latent_channels": 8,
+    "blocks": [["res_x", 1], ["compress_all", 1], ["res_x_y", 1], ["res_x", 1], ["compress_all", 1],
+               ["res_x_y", 1], ["res_x", 1], ["compress_all", 1], ["res_x", 1], ["res_x", 1]],
+    "scaling_factor": 1.0, "norm_layer": "pixel_norm", "patch_size": 4, "latent_log_var": "uniform",
+    "use_quant_conv": False, "causal_decoder": False,
+    "encoder_base_channels": 8, "decoder_base_channels": 8,
+}
+
+
+def tiny_vae_b():
+    cfg = ref_cva.create_video_autoencoder_demo_config(latent_channels=8)
+    cfg["encoder_base_channels"] = 8
+    cfg["decoder_base_channels"] = 8
+    return cfg
+
+
+def jsonable(cfg):
+    return json.loads(json.dumps(cfg))
+
+
+@torch.no_grad()
+def g8_g9():
+    print("G8/G9 conv + blocks")
+    g = torch.Generator().manual_seed(40)
+    t = {}
+    x = torch.randn(2, 6, 4, 5, 7, generator=g)
+    t["x"] = x
+    for mode in ("zeros", "replicate"):
+        torch.manual_seed(41)
+        conv = ref_cc3.CausalConv3d(6, 10, kernel_size=3, spatial_padding_mode=mode)
+        t[f"conv.{mode}.conv.weight"], t[f"conv.{mode}.conv.bias"] = conv.conv.weight, conv.conv.bias
+        t[f"conv.{mode}.causal"] = conv(x, causal=True)
+        t[f"conv.{mode}.noncausal"] = conv(x, causal=False)
+    t["pixel_norm"] = ref_pn.PixelNorm()(x)
+    xp = torch.randn(2, 3, 8, 64, 64, generator=g)[:, :, :2, :16, :16].contiguous()
+    t["patch.x"] = xp
+    t["patch.patchified"] = ref_cva.patchify(xp, patch_size_hw=4, patch_size_t=1)
+    t["patch.roundtrip"] = ref_cva.unpatchify(t["patch.patchified"], patch_size_hw=4, patch_size_t=1)
+
+    torch.manual_seed(42)
+    res = ref_cva.ResnetBlock3D(dims=3, in_channels=8, out_channels=8, eps=1e-6, norm_layer="pixel_norm",
+                                timestep_conditioning=True, spatial_padding_mode="replicate").eval()
+    xr = torch.randn(2, 8, 3, 4, 5, generator=g)
+    temb = torch.randn(2, 32, 1, 1, 1, generator=g) * 0.5
+    t["res.x"], t["res.temb"] = xr, temb
+    t["res.out"] = res(xr, causal=False, timestep=temb)
+    for k, v in res.state_dict().items():
+        t["res.sd." + k] = v
+    torch.manual_seed(43)
+    resxy = ref_cva.ResnetBlock3D(dims=3, in_channels=8, out_channels=4, eps=1e-6, norm_layer="pixel_norm",
+                                  timestep_conditioning=False, spatial_padding_mode="zeros").eval()
+    t["resxy.out"] = resxy(xr, causal=False)
+    for k, v in resxy.state_dict().items():
+        t["resxy.sd." + k] = v
+    torch.manual_seed(44)
+    up = ref_cva.DepthToSpaceUpsample(dims=3, in_channels=8, stride=(2, 2, 2), residual=True,
+                                      out_channels_reduction_factor=2, spatial_padding_mode="replicate").eval()
+    t["up.out"] = up(xr, causal=False)
+    for k, v in up.state_dict().items():
+        t["up.sd." + k] = v
+    torch.manual_seed(45)
+    up2 = ref_cva.DepthToSpaceUpsample(dims=3, in_channels=8, stride=(2, 2, 2), residual=False,
+                                       out_channels_reduction_factor=1, spatial_padding_mode="zeros").eval()
+    t["up2.out"] = up2(xr, causal=False)
+    for k, v in up2.state_dict().items():
+        t["up2.sd." + k] = v
+    save("g8_conv_blocks", t)
+
+
+@torch.no_grad()
+def g10():
+    print("G10 decoder")
+    for tag, cfg in (("a", jsonable(TINY_VAE_A)), ("b", jsonable(tiny_vae_b()))):
+        torch.manual_seed(50)
+        vae = ref_cva.CausalVideoAutoencoder.from_config(json.loads(json.dumps(cfg))).eval()
+        tcond = cfg.get("timestep_conditioning", False)
+        g = torch.Generator().manual_seed(51)
+        C = cfg["latent_channels"]
+        std = 0.5 + torch.rand(C, generator=g)
+        mean = 0.2 * torch.randn(C, generator=g)
+        vae.register_buffer("std_of_means", std)
+        vae.register_buffer("mean_of_means", mean)
+        t = {"per_channel_statistics.std-of-means": std, "per_channel_statistics.mean-of-means": mean}
+        for k, v in vae.state_dict().items():
+            if k.startswith("decoder."):
+                t["sd." + k] = v
+        z = torch.randn(1, C, 2, 2, 2, generator=g)
+        ts = torch.tensor([0.05]) if tcond else None
+        t["z"] = z
+        F_, H, W = z.shape[2:]
+        tgt = (1, 3, (F_ - 1) * 8 + 1, H * 32, W * 32)
+        t["decode"] = vae.decode(z, return_dict=False, target_shape=tgt, timestep=ts)[0]
+        t["vae_decode"] = ref_ve.vae_decode(z, vae, is_video=True, vae_per_channel_normalize=True, timestep=ts)
+        # z-tiling (tile = 4+1 latent frames, vae.py:365-402)
+        zz = torch.randn(1, C, 7, 1, 1, generator=g)
+        t["z_ztile"] = zz
+        vae.enable_z_tiling(4)
+        t["decode_ztile"] = vae.decode(zz, return_dict=False, target_shape=tgt, timestep=ts)[0]
+        vae.disable_z_tiling()
+        t["decode_ztile_ref_untiled"] = vae.decode(zz, return_dict=False, target_shape=tgt, timestep=ts)[0]
+        # hw-tiling with a 64-px tile (tile_latent_min_size = 2), vae.py:223-263
+        zh = torch.randn(1, C, 1, 3, 4, generator=g)
+        t["z_hwtile"] = zh
+        vae.set_tiling_params(sample_size=64, overlap_factor=0.25)
+        vae.enable_hw_tiling()
+        t["decode_hwtile"] = vae.decode(zh, return_dict=False, target_shape=tgt, timestep=ts)[0]
+        vae.disable_hw_tiling()
+        if tcond:
+            t["timestep"] = ts
+        save(f"g10_decoder_{tag}", t, dict(cfg=cfg))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    g1_g2()
+    g3_g4_g5()
+    g6()
+    g8_g9()
+    g10()
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(MANIFEST, f, indent=1, default=list)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
