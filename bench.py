@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- denoise-steps/s (+ VAE-decode frames/s) for LTX-Video 2B t2v 768x512x97 on MI355X.
+
+A "step" is ONE denoise step of BASELINE.json configs[1] on synthetic latents already resident
+in HBM: Transformer3DModel.forward at B_eff = 3 (uncond + text + STG-perturbed rows, as the 2B dev
+YAML enables: guidance 3, stg 1, skip block 19), N = 13*16*24 = 4992 tokens, T = 256 text tokens,
+28 layers, bf16, random-init weights of the 2B architecture, followed by the fused
+CFG-star/STG/rescale + Euler update.  `value` = steps/s over all ranks.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU (RCCL only for the barrier / max-reduce of the clock); each rank
+denoises its own video (replicas; "scaling": "weak").  The JSON line also carries:
+  roofline      the dominant kernel of this workload (the FF up-projection GEMM, MFMA-bound):
+                algorithmic FLOP per launch / average launch time from HIP events recorded on
+                the launch stream inside the timed region
+  attention     the self-attention kernel at this workload and at the north-star stress shape
+                (N = 98304, 1 layer, B = 1): TFLOP/s and fraction of the bf16 MFMA peak on QK^T
+  vae_decode    frames/s of CausalVideoAutoencoder.decode for the same video (z [1,128,13,16,24])
+  cpu_baseline  the CPU oracle (oracle/dit.py, fp32, all host cores) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "ltx-video-gpupoor_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+D, H, DH, L, FF, T_TEXT, C_LAT = 2048, 32, 64, 28, 8192, 256, 128
+GRID = (13, 16, 24)                  # 768x512x97 -> latent frames/height/width
+N_TOK = GRID[0] * GRID[1] * GRID[2]  # 4992
+NUM_CONDS = 3
+
+
+def build_transformer(device, layers=L, seed=0):
+    import ltxmi
+    from oracle.dit import default_2b_config
+    cfg = dict(default_2b_config(), num_layers=layers)
+    torch.manual_seed(seed)
+    with torch.device(device):
+        m = ltxmi.Transformer3DModel(**cfg)
+    for p in m.parameters():                       # module default init, bf16
+        p.requires_grad_(False)
+    return m.to(dtype=torch.bfloat16).eval(), cfg
+
+
+def synth_inputs(device, seed=0):
+    g = torch.Generator(device=device).manual_seed(seed)
+    emb = torch.randn(1, T_TEXT, 4096, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+    neg = torch.randn(1, T_TEXT, 4096, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+    mask = torch.zeros(1, T_TEXT, device=device)
+    mask[:, :96] = 1                               # first 96 tokens valid
+    nmask = torch.zeros(1, T_TEXT, device=device)
+    nmask[:, :8] = 1
+    return emb, mask, neg, nmask
+
+
+class StepRunner:
+    """The loop body of LTXVideoPipeline.__call__ at a fixed timestep schedule position."""
+
+    def __init__(self, device):
+        import ltxmi
+        from ltxmi import ops
+        from oracle import sched
+        self.ops = ops
+        self.ltxmi = ltxmi
+        self.m, self.cfg = build_transformer(device)
+        emb, mask, neg, nmask = synth_inputs(device)
+        self.embeds = torch.cat([neg, emb, emb])
+        self.mask = torch.cat([nmask, mask, mask])
+        g = torch.Generator(device=device).manual_seed(1)
+        self.latents = torch.randn(1, N_TOK, C_LAT, generator=g, device=device, dtype=torch.float32)
+        frac = sched.fractional_coords(*GRID, 1, 25.0).to(device)
+        self.freqs = self.m.precompute_freqs_cis(frac)
+        self.skip = self.m.create_skip_layer_mask(1, NUM_CONDS, NUM_CONDS - 1, [19])
+        self.ws = torch.zeros(8, device=device)
+        ts = sched.set_timesteps(40, (1, C_LAT) + GRID)
+        self.t = float(ts[10])
+        self.dt = float(ts[10] - ts[11])
+        self.t_dev = torch.full((NUM_CONDS, 1), self.t, device=device)
+
+        class Holder:
+            _interrupt = False
+        self.holder = Holder()
+
+    @torch.no_grad()
+    def step(self):
+        x = self.latents.to(torch.bfloat16).expand(NUM_CONDS, -1, -1)
+        noise_pred = self.m(x, freqs_cis=self.freqs, encoder_hidden_states=self.embeds,
+                            encoder_attention_mask=self.mask, timestep=self.t_dev, skip_layer_mask=self.skip,
+                            skip_layer_strategy=self.ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=GRID,
+                            ltxv_model=self.holder, return_dict=False)[0]
+        self.ops.guidance_step_(noise_pred, self.latents, self.dt, 3.0, 1.0, 0.7, True, True, True, self.ws)
+
+
+def time_attention(device, n_tok, iters, B=1):
+    from ltxmi import ops
+    g = torch.Generator(device=device).manual_seed(3)
+    qkv = torch.randn(B, n_tok, 3, H, DH, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+    out = torch.empty(B, n_tok, H, DH, device=device, dtype=torch.bfloat16)
+    ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 4.0 * B * n_tok * n_tok * D                 # QK^T + PV
+    tf = flops / ms / 1e9
+    return {"tokens": n_tok, "batch": B, "ms": round(ms, 3), "tflops": round(tf, 1),
+            "qk_frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+            "algorithmic_bytes": 8 * B * n_tok * D, "note": "QK^T and PV run at the same rate: "
+            "fraction = (4 N^2 D / t) / peak = (2 N^2 D / (t/2)) / peak"}
+
+
+def time_vae(device, iters):
+    import ltxmi
+    from oracle import vae as ov
+    cfg = ov.demo_config(128)                           # the 0.9.5+-style timestep-conditioned decoder
+    torch.manual_seed(5)
+    with torch.device(device):
+        vae = ltxmi.CausalVideoAutoencoder.from_config(dict(cfg))
+    vae = vae.to(dtype=torch.bfloat16).eval()
+    vae.decoder.timestep_scale_multiplier.data = vae.decoder.timestep_scale_multiplier.data.float()
+    z = torch.randn(1, C_LAT, *GRID, device=device).to(torch.bfloat16)
+    ts = torch.tensor([0.05], device=device)
+    with torch.no_grad():
+        img = ltxmi.vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            img = ltxmi.vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    frames = img.shape[2]
+    return {"frames": frames, "shape": list(img.shape), "ms_per_decode": round(dt * 1e3, 2),
+            "frames_per_s": round(frames / dt, 2), "algorithmic_tflop": 24.4,
+            "tflops": round(24.4 / dt, 1)}
+
+
+def cpu_baseline():
+    """The oracle's fp32 restatement of one transformer block (all three sub-layers) at the bench
+    shape for ONE cond, on all host cores; a denoise step is 28 blocks x 3 conds (embeddings,
+    output head, guidance are < 1 % and ignored).  Bounded to about 10-30 s."""
+    from oracle import dit, sched
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = dict(dit.default_2b_config(), num_layers=1)
+    sd = dit.init_state_dict(cfg, seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, N_TOK, D, generator=g)
+    ctx = torch.randn(1, T_TEXT, D, generator=g)
+    temb = torch.randn(1, 1, 6 * D, generator=g) * 0.1
+    bias = torch.zeros(1, 1, T_TEXT)
+    bias[:, :, 96:] = -10000.0
+    fc = dit.precompute_freqs_cis(sched.fractional_coords(*GRID, 1, 25.0), cfg, torch.float32)
+    with torch.no_grad():
+        dit.transformer_block(sd, "transformer_blocks.0.", cfg, x, fc, ctx, bias, temb)      # warm
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 3 and time.perf_counter() - t0 < 25:
+            dit.transformer_block(sd, "transformer_blocks.0.", cfg, x, fc, ctx, bias, temb)
+            reps += 1
+    per_block = (time.perf_counter() - t0) / reps
+    return {"value": round(1.0 / (per_block * L * NUM_CONDS), 6), "unit": "denoise-steps/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps}x one transformer block (fp32 oracle) at N=4992, 1 cond: {per_block:.2f} s/block, "
+                      f"extrapolated x{L} blocks x{NUM_CONDS} conds"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-extras", action="store_true", help="skip attention-stress / VAE / CPU legs")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from ltxmi import ops
+    runner = StepRunner(device)
+    M = NUM_CONDS * N_TOK
+    key_ff1 = ("gemm", M, FF, D, ops.EPI_GELU_TANH)
+    key_attn = ("attention", NUM_CONDS, H, N_TOK, N_TOK, DH)
+
+    for _ in range(args.warmup):
+        runner.step()
+    ops.watch_launches([key_ff1, key_attn])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    times = ops.launch_times_ms()
+    ops.watch_launches(None)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    assert torch.isfinite(runner.latents).all(), "non-finite latents after the timed steps"
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+
+    if rank == 0:
+        ff1 = times.get(key_ff1, [])
+        ff1_ms = sum(ff1) / max(len(ff1), 1)
+        ff1_flop = 2.0 * M * FF * D
+        achieved = ff1_flop / (ff1_ms * 1e-3) / 1e12 if ff1_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("ff1_gemm_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        at = times.get(key_attn, [])
+        at_ms = sum(at) / max(len(at), 1)
+        at_tf = 4.0 * NUM_CONDS * N_TOK * N_TOK * D / (at_ms * 1e-3) / 1e12 if at_ms > 0 else 0.0
+        line = {
+            "metric": "denoise-steps/sec + VAE-decode frames/sec, LTX-Video 768x512x97f at 1/8 GPU",
+            "value": round(value, 4), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "LTX-Video 2B t2v 768x512x97, one denoise step = Transformer3DModel.forward "
+                                   "(28 layers, D 2048, 32x64 heads, N 4992 tokens, T 256) at B_eff 3 "
+                                   "(CFG + STG rows) + fused guidance/Euler; random-init weights",
+                       "tokens": N_TOK, "b_eff": NUM_CONDS, "layers": L, "parallelism": f"replicas x{world}",
+                       "algorithmic_tflop_per_step": 66.4},
+            "step_tflops": round(66.4 / (ms_per_step * 1e-3), 1),
+            "roofline": {"kernel": "gemm_bf16_nt_kernel<256,256,2,4,GELU_TANH> (ff.net.0, M=14976 N=8192 K=2048)",
+                         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "traffic": traffic, "launch_ms": round(ff1_ms, 4), "launches_timed": len(ff1),
+                         "algorithmic_flop_per_launch": ff1_flop},
+            "attention": {"workload": {"tokens": N_TOK, "batch": NUM_CONDS, "ms": round(at_ms, 4),
+                                       "tflops": round(at_tf, 1),
+                                       "qk_frac_of_mfma_peak": round(at_tf / MFMA_BF16_PEAK_TFLOPS, 4)}},
+        }
+        if not args.no_extras and world == 1:
+            del runner
+            torch.cuda.empty_cache()
+            line["attention"]["stress_98304"] = time_attention(device, 98304, 2)
+            line["attention"]["tokens_13376"] = time_attention(device, 13376, 5)
+            line["vae_decode"] = time_vae(device, 2)
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

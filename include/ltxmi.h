@@ -1,0 +1,220 @@
+/*
+ * ltxmi.h -- C ABI of libltxmi.so: the MI355X (gfx950) kernels of the LTX-Video
+ * denoise hot path (DiT forward + causal 3-D VAE decode).
+ *
+ * The reference project (soasme/LTX-Video-GPUPoor) is 100 % Python and has no FFI of
+ * its own: every entry point below replaces a PyTorch / third-party-wheel call made
+ * by the reference at the cited file:line.  INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add at each of those sites.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless named host_*; caller-allocated;
+ *     nothing is allocated, freed or synchronised inside the library;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are
+ *     enqueued on it and the call returns immediately; re-entrant per stream;
+ *   - bf16 tensors are raw uint16 payloads (torch.bfloat16 storage), row-major,
+ *     innermost dimension contiguous; "ld*" arguments are row strides in ELEMENTS;
+ *   - return value: 0 = LTXMI_OK, negative = ltxmi_status; ltxmi_last_error() returns
+ *     a thread-local message for the last failing call.  Unsupported shapes are an
+ *     error -- there is no fallback path of any kind.
+ */
+#ifndef LTXMI_H
+#define LTXMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ltxmi_status {
+    LTXMI_OK = 0,
+    LTXMI_ERR_INVALID_ARG = -1,   /* NULL pointer, non-positive size, bad enum            */
+    LTXMI_ERR_UNSUPPORTED = -2,   /* shape / alignment outside what the kernels handle    */
+    LTXMI_ERR_LAUNCH = -3         /* hipGetLastError() != hipSuccess after the launch     */
+} ltxmi_status;
+
+/* Library identification and error text. */
+const char* ltxmi_version(void);
+const char* ltxmi_last_error(void);
+/* Name of the gfx target the kernels were compiled for ("gfx950"). */
+const char* ltxmi_arch(void);
+
+/* ---------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N])       bf16 in, fp32 acc, bf16 out
+ *
+ * Replaces nn.Linear (+ the elementwise ops the reference runs right after it):
+ *   to_q/to_k/to_v, to_out[0]      ltx_video/models/transformers/attention.py:1040-1059,1147
+ *   ff.net[0] (Linear+GELU-tanh)   attention.py:339       ff.net[2]  attention.py:340
+ *   gate * x ; hidden += x         attention.py:282-288, 345-351, 310
+ *   patchify_proj / proj_out       ltx_video/models/transformers/transformer3d.py:418,503
+ *   adaln_single / caption_projection linears   transformer3d.py:428-433,448
+ * W is the nn.Linear weight as stored in the checkpoint ([out,in], K contiguous).
+ * Requirements: K % 64 == 0, N % 8 == 0, all pointers 16-byte aligned, lda/ldw/ldc % 8 == 0.
+ * ------------------------------------------------------------------------------- */
+typedef enum ltxmi_epilogue {
+    LTXMI_EPI_NONE = 0,       /* C = acc + bias                                              */
+    LTXMI_EPI_GELU_TANH = 1,  /* C = gelu_tanh(acc + bias)                                   */
+    LTXMI_EPI_SILU = 2,       /* C = silu(acc + bias)                                        */
+    LTXMI_EPI_GATE_RESIDUAL = 3 /* C = R + gate * (acc + bias); R may alias C (in place)
+                                   gate[r, n] = gate_table[n] + gate_temb[(r / rows_per_group) * gate_ld + n]
+                                   (AdaLN-Zero gate, attention.py:239-246); gate_table == NULL -> gate = 1 */
+} ltxmi_epilogue;
+
+typedef struct ltxmi_gemm_args {
+    const void* A;  int64_t lda;      /* [M,K] bf16                                         */
+    const void* W;  int64_t ldw;      /* [N,K] bf16                                         */
+    const void* bias;                 /* [N] bf16 or NULL                                   */
+    void*       C;  int64_t ldc;      /* [M,N] bf16                                         */
+    int32_t M, N, K;
+    int32_t epilogue;                 /* ltxmi_epilogue                                     */
+    const void* residual; int64_t ldr;/* [M,N] bf16, GATE_RESIDUAL only                     */
+    const void* gate_table;           /* [N] bf16 (row of scale_shift_table) or NULL        */
+    const void* gate_temb;            /* bf16, row g at gate_temb + g*gate_ld               */
+    int64_t     gate_ld;
+    int32_t     rows_per_group;       /* tokens sharing one modulation row (N_tok / T1)     */
+} ltxmi_gemm_args;
+
+int ltxmi_gemm_bf16(const ltxmi_gemm_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused standardisation + AdaLN modulation
+ *   y = norm(x) * (1 + scale) + shift,   norm = RMSNorm (no affine) or LayerNorm (no affine)
+ *   scale[r,c] = scale_table[c] + scale_temb[g*temb_ld + c],  g = r / rows_per_group (same for shift)
+ * Replaces norm1/norm2 + `*= 1+scale; += shift`  attention.py:233-251, 314-320 and
+ * norm_out + modulation transformer3d.py:489-502 (kind = LTXMI_NORM_LAYER).
+ * D % 8 == 0, D <= 8192.
+ * ------------------------------------------------------------------------------- */
+typedef enum ltxmi_norm_kind { LTXMI_NORM_RMS = 0, LTXMI_NORM_LAYER = 1 } ltxmi_norm_kind;
+
+int ltxmi_norm_modulate_bf16(const void* x, int64_t ldx, void* y, int64_t ldy,
+                             int32_t rows, int32_t D, float eps, int32_t kind,
+                             const void* scale_table, const void* scale_temb,
+                             const void* shift_table, const void* shift_temb,
+                             int64_t temb_ld, int32_t rows_per_group, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * q/k RMSNorm across heads (+weight, eps) followed by interleaved-pair RoPE on the flat
+ * channel axis; in place.   attention.py:1041,1048,1052 (q_norm/k_norm = diffusers RMSNorm
+ * over heads*dim_head, attention.py:478-479) and apply_rotary_emb attention.py:960-975.
+ * x: [rows, D] (row stride ldx); cos/sin: [rope_rows, D] bf16 with row index
+ * (r % rope_period) -- rope_period = tokens per sample when the table is shared over the
+ * batch; cos == NULL -> no rotation (cross-attention).  weight: [D] bf16.
+ * ------------------------------------------------------------------------------- */
+int ltxmi_rmsnorm_rope_bf16(void* x, int64_t ldx, int32_t rows, int32_t D,
+                            const void* weight, float eps,
+                            const void* cos_tab, const void* sin_tab, int64_t ld_tab,
+                            int32_t rope_period, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Flash attention forward (non-causal, softmax scale given), bf16 in/out, fp32 softmax.
+ * Replaces pay_attention(..)'s eager branch = F.scaled_dot_product_attention
+ *   wan/modules/attention.py:162-199, 344-347 -> sdpa_wrapper :99-116
+ * called from AttnProcessor2_0 at attention.py:1112-1119 (self) and, with the additive
+ * key bias built at transformer3d.py:411-415, for T5 cross-attention (attention.py:303-309).
+ * Layout NHD like the seam: element (b, l, h, d) at  base + b*stride_b + l*stride_l + h*head_dim + d
+ * (strides in elements; lets q,k,v alias slices of one fused [B,L,3*H*dh] projection buffer).
+ * key_bias: optional fp32 [B, Lk] added to the scaled scores (broadcast over heads and queries).
+ * head_dim in {64, 128}; Lq, Lk >= 1 (ragged tails are masked inside the kernel).
+ * ------------------------------------------------------------------------------- */
+typedef struct ltxmi_attn_args {
+    const void* q; int64_t q_stride_b, q_stride_l;
+    const void* k; int64_t k_stride_b, k_stride_l;
+    const void* v; int64_t v_stride_b, v_stride_l;
+    void*       o; int64_t o_stride_b, o_stride_l;
+    const float* key_bias; int64_t bias_stride_b;   /* NULL = no bias */
+    int32_t B, H, Lq, Lk, head_dim;
+    float   softmax_scale;
+} ltxmi_attn_args;
+
+int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Small elementwise helpers on the DiT path.
+ * ------------------------------------------------------------------------------- */
+/* y = silu(x) (kind 0) -- AdaLayerNormSingle's SiLU between its linears, transformer3d.py:428. */
+int ltxmi_silu_bf16(const void* x, void* y, int64_t n, void* stream);
+/* Sinusoidal timestep projection (256 ch, flip_sin_to_cos, shift 0) -> bf16 [n,256];
+ * t is fp32 [n] ALREADY multiplied by timestep_scale_multiplier.
+ * ltx_video/models/transformers/embeddings.py:10-50 as used by AdaLayerNormSingle. */
+int ltxmi_timestep_embedding_bf16(const float* t, void* out, int32_t n, int32_t dim, void* stream);
+/* STG "attention values" blend: a = a*m[b] + v*(1-m[b]),  attention.py:1134-1141.
+ * a: [B, L, D] contiguous rows lda; v rows ldv; m fp32 [B]. */
+int ltxmi_stg_blend_bf16(void* a, int64_t lda, const void* v, int64_t ldv,
+                         const float* m, int32_t B, int32_t L, int32_t D, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * VAE decode kernels (channels-last NDHWC activations, bf16).
+ * ------------------------------------------------------------------------------- */
+/* 3x3x3 stride-1 convolution as implicit GEMM with the reference's padding semantics
+ * folded into the address computation:
+ *   time:  replicate (k-1) frames in front when causal, else (k-1)/2 on both sides
+ *          ltx_video/models/autoencoders/causal_conv3d.py:44-59
+ *   space: pad 1, zeros or replicate (nn.Conv3d padding_mode)   causal_conv3d.py:33-42
+ * x: [B, T, H, W, Cin]; w: [Cout, 27, Cin] (tap-major, K contiguous; repacked from the
+ * checkpoint's [Cout,Cin,3,3,3] once at load); bias [Cout]; y: [B, T, H, W, Cout].
+ * Optional fused output transform (DepthToSpaceUpsample, causal_video_autoencoder.py:1051-1065):
+ *   d2s = 1 -> the Cout = 8*C' channels are scattered as (c p1 p2 p3) into
+ *   y: [B, 2T-1, 2H, 2W, C'] (first output frame dropped) and, if residual != NULL,
+ *   the pixel-shuffled, channel-repeated input is added (res_repeat = 8 / reduction).
+ * Cin % 64 == 0; Cout % 8 == 0.
+ * ------------------------------------------------------------------------------- */
+typedef struct ltxmi_conv3d_args {
+    const void* x; const void* w; const void* bias; void* y;
+    int32_t B, T, H, W, Cin, Cout;
+    int32_t causal;            /* 1: replicate 2 frames in front; 0: 1 + 1                */
+    int32_t pad_replicate;     /* spatial padding mode: 0 zeros, 1 replicate              */
+    int32_t d2s;               /* 0 plain NDHWC store, 1 depth-to-space (2,2,2) store     */
+    const void* residual;      /* d2s only: x itself (pre-conv block input) or NULL       */
+    int32_t res_channels;      /* channels of the residual tensor (Cin of the block)      */
+    const void* add;           /* plain store only: y = conv + add, add [B,T,H,W,Cout] or NULL
+                                  (ResnetBlock3D skip, causal_video_autoencoder.py:1256)   */
+} ltxmi_conv3d_args;
+
+int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* args, void* stream);
+
+/* PixelNorm (pixel_norm.py:5-12, eps 1e-8) -> optional (1+scale)*x+shift per (batch, channel)
+ * (ResnetBlock3D AdaLN, causal_video_autoencoder.py:1206-1243, Decoder tail :771-795)
+ * -> optional SiLU; NDHWC rows of C channels; scale/shift fp32 [B, C] or NULL.
+ * rows_per_batch = T*H*W.  C % 8 == 0, C <= 4096. */
+int ltxmi_pixelnorm_ada_silu_bf16(const void* x, void* y, int64_t rows, int32_t C,
+                                  int64_t rows_per_batch, const float* scale, const float* shift,
+                                  int32_t apply_silu, float eps, void* stream);
+
+/* y = a + b elementwise (ResnetBlock3D skip add, causal_video_autoencoder.py:1256). */
+int ltxmi_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+
+/* Channel LayerNorm with affine over NDHWC rows (norm3 of res_x_y blocks,
+ * causal_video_autoencoder.py:1068-1077,1170-1174). */
+int ltxmi_layernorm_affine_bf16(const void* x, void* y, int64_t rows, int32_t C,
+                                const void* gamma, const void* beta, float eps, void* stream);
+
+/* Layout changes at the decoder boundary:
+ *  ncdhw_to_ndhwc: latent z [B,C,T,H,W] (any float bf16) * std[c] + mean[c] -> NDHWC bf16
+ *                  (un_normalize_latents, vae_encode.py:239-247; std == NULL -> plain copy)
+ *  unpatchify:     conv_out result NDHWC [B,T,H,W,3*p*p] -> pixels NCDHW [B,3,T,H*p,W*p]
+ *                  "b (c p r q) f h w -> b c (f p) (h q) (w r)" with p=1 (causal_video_autoencoder.py:1282-1299) */
+int ltxmi_ncdhw_to_ndhwc_bf16(const void* z, void* y, int32_t B, int32_t C, int32_t T, int32_t H,
+                              int32_t W, const float* std, const float* mean, void* stream);
+int ltxmi_unpatchify_to_ncdhw_bf16(const void* x, void* y, int32_t B, int32_t T, int32_t H, int32_t W,
+                                   int32_t C_out, int32_t patch, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Denoise-loop step math kept on device (no host sync per step).
+ *   guidance: CFG-star + STG + std-rescale  pipeline_ltx_video.py:1183-1222
+ *   euler   : x <- x - dt * v               ltx_video/schedulers/rf.py:375
+ * noise_pred: bf16 [num_conds, n] (one sample, chunk order uncond/text/perturbed as built at
+ * pipeline_ltx_video.py:1035-1051); latents: [n], fp32 (latents_bf16 = 0) or bf16 (= 1).
+ * workspace: >= 8 floats, zeroed by the call (stream-ordered memset).
+ * ------------------------------------------------------------------------------- */
+int ltxmi_guidance_step_bf16(const void* noise_pred, int64_t n, int32_t num_conds,
+                             float guidance_scale, float stg_scale, float rescaling_scale,
+                             int32_t do_cfg, int32_t do_stg, int32_t do_rescale,
+                             void* latents, int32_t latents_bf16, float dt, float* workspace,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTXMI_H */

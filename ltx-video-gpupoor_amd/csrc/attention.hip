@@ -1,0 +1,326 @@
+// attention.hip -- flash-style attention forward for the pay_attention() seam.
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query
+// rows and walks the keys in tiles of 64.  Per tile and wave:
+//
+//   S^T[key][query]  = K . Q^T          v_mfma_f32_32x32x16_bf16, A = K tile (LDS, ds_read_b128),
+//                                        B = Q^T (registers, loaded once)
+//   online softmax                        entirely in registers: the SWAPPED product leaves the
+//                                        query on the lane (col = lane&31) and 16 of the tile's
+//                                        keys in that lane's 16 accumulator registers, so the
+//                                        row max / row sum are in-lane reductions plus ONE
+//                                        v_permlane32_swap with the partner lane (lane^32)
+//   O^T[d][query]   += V^T . P^T         A = V^T via ds_read_b64_tr_b16 (hardware transposed LDS
+//                                        read), B = P^T = the S^T accumulator registers converted
+//                                        pairwise to bf16 (no LDS round trip, no lane movement)
+//
+// Both products keep the query on the lane, so m, l and the O rescale factor are lane-local.
+//
+// LDS: K image = rows of DH bf16, 16-byte chunk c of row r at slot c ^ swz(r) (swz chosen so
+// the 16-lane ds_read_b128 groups of the 32x32x16 A operand hit 16 distinct slots);
+// V image = [8 key][32 col] sub-tiles of 512 B, which makes each 32-lane half of a transposed
+// read cover 256 contiguous bytes (conflict-free).  K/V tiles are register-staged
+// (global_load_dwordx4 issued before the tile's MFMAs, ds_write_b128 after them: the "async
+// STAGE split"), two LDS buffers, one barrier per tile.
+//
+// Work mapping is XCD-aware: each XCD walks whole (batch, head) pairs, so the 32 CUs that share
+// an L2 stream the same K/V at the same time.
+#include "common.h"
+
+namespace ltxmi {
+
+struct AttnParams {
+    const uint16_t* q; int64_t q_sb, q_sl;
+    const uint16_t* k; int64_t k_sb, k_sl;
+    const uint16_t* v; int64_t v_sb, v_sl;
+    uint16_t* o; int64_t o_sb, o_sl;
+    const float* bias; int64_t bias_sb;
+    int B, H, Lq, Lk;
+    float scale_log2e;   // softmax_scale * log2(e)
+    int q_tiles;         // ceil(Lq / 128)
+};
+
+constexpr int KV_TILE = 64;
+constexpr int Q_PER_WAVE = 32;
+constexpr int Q_PER_WG = 128;
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int DH>
+struct AttnCfg {
+    static constexpr int ROW_BYTES = DH * 2;
+    static constexpr int TILE_BYTES = KV_TILE * DH * 2;         // one K or V tile
+    static constexpr int CHUNKS_PER_ROW = DH / 8;               // 16-byte chunks per key row
+    static constexpr int LD_PER_THREAD = (KV_TILE * CHUNKS_PER_ROW) / 256;
+    static constexpr int KSTEPS = DH / 16;                      // QK^T MFMA k-steps
+    static constexpr int DBLK = DH / 32;                        // O^T row blocks
+    static constexpr int BIAS_BYTES = KV_TILE * 4;
+    static constexpr int STAGE_BYTES = 2 * TILE_BYTES + BIAS_BYTES;
+    static constexpr int SMEM = 2 * STAGE_BYTES;
+    __device__ static __forceinline__ int k_swz(int row) {
+        return DH == 64 ? ((row >> 1) & 7) : (row & 15);
+    }
+};
+
+template <int DH, bool HAS_BIAS>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+    using C = AttnCfg<DH>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;      // query column of this lane
+    const int hh = lane >> 5;     // which 4-row group of every 8 accumulator rows
+
+    // ---- XCD-aware work id (bijective chunking, see gemm.hip)
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qn = nwg >> 3, rn = nwg & 7;
+    const int work = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
+    const int bh = work / p.q_tiles, qt = work % p.q_tiles;
+    const int b = bh / p.H, head = bh % p.H;
+
+    const uint16_t* qb = p.q + (int64_t)b * p.q_sb + head * DH;
+    const uint16_t* kb_ = p.k + (int64_t)b * p.k_sb + head * DH;
+    const uint16_t* vb = p.v + (int64_t)b * p.v_sb + head * DH;
+    uint16_t* ob = p.o + (int64_t)b * p.o_sb + head * DH;
+    const float* biasb = HAS_BIAS ? p.bias + (int64_t)b * p.bias_sb : nullptr;
+
+    // ---- Q^T fragments (B operand): lane (r, hh), k-step s holds Q[q][16 s + 8 hh .. +7]
+    const int q_row = qt * Q_PER_WG + wave * Q_PER_WAVE + r;
+    const int q_ld = q_row < p.Lq ? q_row : p.Lq - 1;
+    bf16x8 qf[C::KSTEPS];
+#pragma unroll
+    for (int s = 0; s < C::KSTEPS; ++s)
+        qf[s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * hh);
+
+    // ---- staging geometry: thread handles chunks c = tid + 256 i of the [64][DH/8] tile
+    int st_key[C::LD_PER_THREAD], st_koff[C::LD_PER_THREAD], st_voff[C::LD_PER_THREAD], st_col[C::LD_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < C::LD_PER_THREAD; ++i) {
+        const int c = tid + 256 * i;
+        const int key = c / C::CHUNKS_PER_ROW, dc = c % C::CHUNKS_PER_ROW;
+        st_key[i] = key;
+        st_col[i] = dc * 8;
+        st_koff[i] = key * C::ROW_BYTES + ((dc ^ C::k_swz(key)) << 4);
+        st_voff[i] = C::TILE_BYTES + ((key >> 3) * C::DBLK + (dc >> 2)) * 512 + (key & 7) * 64 + (dc & 3) * 16;
+    }
+    u32x4 kreg[C::LD_PER_THREAD], vreg[C::LD_PER_THREAD];
+    float breg = 0.f;
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < C::LD_PER_THREAD; ++i) {
+            int key = k0 + st_key[i];
+            key = key < p.Lk ? key : p.Lk - 1;
+            kreg[i] = *(const u32x4*)(kb_ + (int64_t)key * p.k_sl + st_col[i]);
+            vreg[i] = *(const u32x4*)(vb + (int64_t)key * p.v_sl + st_col[i]);
+        }
+        if (HAS_BIAS && tid < KV_TILE) {
+            const int key = k0 + tid;
+            breg = key < p.Lk ? biasb[key] * LOG2E : 0.f;
+        }
+    };
+    auto write_tile = [&](int buf) {
+        char* s = smem + buf * C::STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::LD_PER_THREAD; ++i) {
+            *(u32x4*)(s + st_koff[i]) = kreg[i];
+            *(u32x4*)(s + st_voff[i]) = vreg[i];
+        }
+        if (HAS_BIAS && tid < KV_TILE) *(float*)(s + 2 * C::TILE_BYTES + tid * 4) = breg;
+    };
+
+    // ---- per-lane LDS read offsets
+    // K (A operand of QK^T): row 32 kb + r, chunk 2 s + hh
+    int k_rd[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) k_rd[kb] = (32 * kb + r) * C::ROW_BYTES;
+    const int k_sw0 = C::k_swz(r);                 // swz(32 + r) == swz(r) for both head dims
+    // V^T (A operand of PV) via transposed reads: block rows 16 s' + 4 hh + q (+8), cols 32 db + r
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int v_rd = C::TILE_BYTES + (4 * (g16 >> 1) + (i16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+
+    f32x16 oT[C::DBLK];
+#pragma unroll
+    for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oT[d][e] = 0.f;
+    float m_run = -INFINITY;   // running max: raw scores (no bias) or scaled+biased log2 domain (bias)
+    float l_run = 0.f;         // this lane's share of the running row sum
+    const float c = p.scale_log2e;
+
+    const int nt = (p.Lk + KV_TILE - 1) / KV_TILE;
+    load_tile(0);
+    write_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        const char* s = smem + cur * C::STAGE_BYTES;
+        if (t + 1 < nt) load_tile((t + 1) * KV_TILE);
+
+        // ---------------- S^T = K Q^T
+        f32x16 sT[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sT[kb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C::KSTEPS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(s + k_rd[kb] + (((2 * ks + hh) ^ k_sw0) << 4));
+                sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sT[kb], 0, 0, 0);
+            }
+        }
+
+        // ---------------- scores -> log2 domain, mask, running max
+        const int k0 = t * KV_TILE;
+        const bool tail = (k0 + KV_TILE > p.Lk);
+        if (HAS_BIAS) {
+            const float* bl = (const float*)(s + 2 * C::TILE_BYTES);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b4 = *(const f32x4*)(bl + 32 * kb + 8 * g + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sT[kb][4 * g + e] = sT[kb][4 * g + e] * c + b4[e];
+                }
+        }
+        if (tail) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = k0 + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (key >= p.Lk) sT[kb][e] = -INFINITY;
+                }
+        }
+        float mt = sT[0][0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mt = fmaxf(mt, sT[0][e]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sT[1][e]);
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_new = fmaxf(m_run, mt);
+        float alpha, moff;
+        if (HAS_BIAS) {
+            alpha = fast_exp2(m_run - m_new);
+            moff = m_new;
+        } else {
+            alpha = fast_exp2((m_run - m_new) * c);
+            moff = m_new * c;
+        }
+        m_run = m_new;
+
+        // ---------------- P = exp2(x - m), row sum, bf16 fragments
+        float lsum = 0.f;
+        bf16x8 pf[4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float x = HAS_BIAS ? (sT[kb][e] - moff) : (sT[kb][e] * c - moff);
+                const float pe = fast_exp2(x);
+                sT[kb][e] = pe;
+                lsum += pe;
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[2 * kb + h2][e] = (__bf16)sT[kb][8 * h2 + e];
+        }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oT[d][e] *= alpha;
+
+        // ---------------- O^T += V^T P^T
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {
+#pragma unroll
+            for (int d = 0; d < C::DBLK; ++d) {
+                const char* base = s + v_rd + (2 * sp * C::DBLK + d) * 512;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(base));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(base + C::DBLK * 512));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+                oT[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sp], oT[d], 0, 0, 0);
+            }
+        }
+
+        if (t + 1 < nt) write_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: O = O^T / l
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = 1.0f / l_run;
+    if (q_row < p.Lq) {
+        uint16_t* orow = ob + (int64_t)q_row * p.o_sl;
+#pragma unroll
+        for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w[0] = pack_bf16(oT[d][4 * g + 0] * inv, oT[d][4 * g + 1] * inv);
+                w[1] = pack_bf16(oT[d][4 * g + 2] * inv, oT[d][4 * g + 3] * inv);
+                *(u32x2*)(orow + 32 * d + 8 * g + 4 * hh) = w;
+            }
+    }
+}
+
+template <int DH, bool HAS_BIAS>
+static int launch(const AttnParams& p, hipStream_t stream) {
+    using C = AttnCfg<DH>;
+    auto kern = attn_fwd_kernel<DH, HAS_BIAS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        attr_set = true;
+    }
+    const int grid = p.B * p.H * p.q_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::SMEM, stream, p);
+    return check_launch("ltxmi_attention_fwd_bf16");
+}
+
+}  // namespace ltxmi
+
+using namespace ltxmi;
+
+extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) {
+    LTXMI_REQUIRE(a && a->q && a->k && a->v && a->o, LTXMI_ERR_INVALID_ARG, "ltxmi_attention_fwd_bf16: NULL argument");
+    LTXMI_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_attention_fwd_bf16: non-positive shape B=%d H=%d Lq=%d Lk=%d", a->B, a->H, a->Lq, a->Lk);
+    LTXMI_REQUIRE(a->head_dim == 64 || a->head_dim == 128, LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_attention_fwd_bf16: head_dim %d not in {64, 128}", a->head_dim);
+    const int64_t strides[] = {a->q_stride_b, a->q_stride_l, a->k_stride_b, a->k_stride_l,
+                               a->v_stride_b, a->v_stride_l, a->o_stride_b, a->o_stride_l};
+    for (int64_t s : strides)
+        LTXMI_REQUIRE(s % 8 == 0, LTXMI_ERR_UNSUPPORTED, "ltxmi_attention_fwd_bf16: strides must be multiples of 8 elements");
+    LTXMI_REQUIRE((((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->o) & 15) == 0,
+                  LTXMI_ERR_UNSUPPORTED, "ltxmi_attention_fwd_bf16: q/k/v/o must be 16-byte aligned");
+    LTXMI_REQUIRE((int64_t)a->B * a->H * ((a->Lq + Q_PER_WG - 1) / Q_PER_WG) < (1ll << 31), LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_attention_fwd_bf16: grid too large");
+    AttnParams p;
+    p.q = (const uint16_t*)a->q; p.q_sb = a->q_stride_b; p.q_sl = a->q_stride_l;
+    p.k = (const uint16_t*)a->k; p.k_sb = a->k_stride_b; p.k_sl = a->k_stride_l;
+    p.v = (const uint16_t*)a->v; p.v_sb = a->v_stride_b; p.v_sl = a->v_stride_l;
+    p.o = (uint16_t*)a->o; p.o_sb = a->o_stride_b; p.o_sl = a->o_stride_l;
+    p.bias = a->key_bias; p.bias_sb = a->bias_stride_b;
+    p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk;
+    p.scale_log2e = a->softmax_scale * LOG2E;
+    p.q_tiles = (a->Lq + Q_PER_WG - 1) / Q_PER_WG;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->head_dim == 64) return a->key_bias ? launch<64, true>(p, s) : launch<64, false>(p, s);
+    return a->key_bias ? launch<128, true>(p, s) : launch<128, false>(p, s);
+}

@@ -1,0 +1,75 @@
+// common.h -- shared device helpers for libltxmi (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ltxmi.h"
+
+namespace ltxmi {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;      // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;        // 16x16 accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;      // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+constexpr int WAVE = 64;
+
+// ---- bf16 <-> f32 ------------------------------------------------------------
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+// plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+// ---- activations ---------------------------------------------------------------
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.0f + fast_exp2(-1.44269504f * x)); }
+// gelu(tanh): 0.5 x (1 + tanh(u)) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float u = 0.7978845608f * (x + 0.044715f * x * x * x);
+    return x * fast_rcp(1.0f + fast_exp2(-2.88539008f * u));
+}
+
+// ---- wave reductions -----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void_ptr)gsrc, (lds_void_ptr)lds_wave_base, 16, 0, 0);
+}
+
+// ---- host-side error plumbing --------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+}  // namespace ltxmi
+
+#define LTXMI_REQUIRE(cond, code, ...)          \
+    do {                                        \
+        if (!(cond)) {                          \
+            ltxmi::set_error(__VA_ARGS__);      \
+            return (code);                      \
+        }                                       \
+    } while (0)

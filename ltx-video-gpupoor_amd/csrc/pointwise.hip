@@ -1,0 +1,270 @@
+// pointwise.hip -- small elementwise / layout / step-math kernels (all HBM-bound or tiny).
+#include <math.h>
+
+#include "common.h"
+
+namespace ltxmi {
+
+constexpr int PW_THREADS = 256;
+static inline unsigned pw_grid(int64_t work_items) {
+    int64_t g = (work_items + PW_THREADS - 1) / PW_THREADS;
+    const int64_t cap = 256 * 8;   // 8 blocks per CU, grid-stride beyond that
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// y = silu(x), 8 elements (16 B) per thread-iteration; n % 8 == 0
+__global__ void silu_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t nchunks) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4 w = *(const u32x4*)(x + i * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack_bf16(silu_f(bf_lo(w[k])), silu_f(bf_hi(w[k])));
+        *(u32x4*)(y + i * 8) = o;
+    }
+}
+
+__global__ void add_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ y,
+                           int64_t nchunks) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * blockDim.x) {
+        const u32x4 u = *(const u32x4*)(a + i * 8);
+        const u32x4 v = *(const u32x4*)(b + i * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack_bf16(bf_lo(u[k]) + bf_lo(v[k]), bf_hi(u[k]) + bf_hi(v[k]));
+        *(u32x4*)(y + i * 8) = o;
+    }
+}
+
+// sinusoid: out[i, :half] = cos(t_i * f_k), out[i, half:] = sin(t_i * f_k), f_k = exp(-ln(1e4) k / half)
+// (flip_sin_to_cos=True, downscale_freq_shift=0: embeddings.py:29-45)
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, uint16_t* __restrict__ out, int n, int dim) {
+    const int half = dim >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * half) return;
+    const int i = idx / half, k = idx % half;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half);
+    const float a = t[i] * f;
+    out[(int64_t)i * dim + k] = f2bf(cosf(a));
+    out[(int64_t)i * dim + half + k] = f2bf(sinf(a));
+}
+
+// a = a*m[b] + v*(1-m[b])
+__global__ void stg_blend_kernel(uint16_t* __restrict__ a, int64_t lda, const uint16_t* __restrict__ v, int64_t ldv,
+                                 const float* __restrict__ m, int L, int D, int64_t total_chunks) {
+    const int cpr = D >> 3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_chunks;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int ch = (int)(i % cpr);
+        const float mm = m[row / L];
+        if (mm == 1.0f) continue;
+        uint16_t* ap = a + row * lda + ch * 8;
+        const u32x4 u = *(const u32x4*)ap;
+        const u32x4 w = *(const u32x4*)(v + row * ldv + ch * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = pack_bf16(bf_lo(u[k]) * mm + bf_lo(w[k]) * (1.f - mm), bf_hi(u[k]) * mm + bf_hi(w[k]) * (1.f - mm));
+        *(u32x4*)ap = o;
+    }
+}
+
+// z [B,C,T,H,W] bf16 -> y [B,T,H,W,C] bf16, optionally * std[c] + mean[c]
+__global__ void ncdhw_to_ndhwc_kernel(const uint16_t* __restrict__ z, uint16_t* __restrict__ y, int C, int64_t thw,
+                                      int64_t total, const float* __restrict__ std, const float* __restrict__ mean) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pos = (i / C) % thw;
+        const int64_t b = i / ((int64_t)C * thw);
+        float v = bf2f(z[(b * C + c) * thw + pos]);
+        if (std) v = v * std[c] + mean[c];
+        y[i] = f2bf(v);
+    }
+}
+
+// x [B,T,H,W, C_out*p*p] (channel n = (c*p + r)*p + q) -> y [B,C_out,T,H*p,W*p], pixel (h*p+q, w*p+r)
+__global__ void unpatchify_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int T, int H, int W,
+                                  int Co, int P, int64_t total) {
+    const int Wp = W * P, Hp = H * P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wp);
+        const int yo = (int)((i / Wp) % Hp);
+        const int t = (int)((i / ((int64_t)Wp * Hp)) % T);
+        const int c = (int)((i / ((int64_t)Wp * Hp * T)) % Co);
+        const int64_t b = i / ((int64_t)Wp * Hp * T * Co);
+        const int w = xo / P, r = xo % P, h = yo / P, q = yo % P;
+        const int n = (c * P + r) * P + q;
+        y[i] = x[(((b * T + t) * H + h) * W + w) * ((int64_t)Co * P * P) + n];
+    }
+}
+
+// ---------------------------------------------------------------- guidance + Euler step
+// ws[0]=sum(text*uncond) ws[1]=sum(uncond^2) ws[2]=sum(text) ws[3]=sum(text^2) ws[4]=sum(out) ws[5]=sum(out^2)
+struct GuidanceP {
+    const uint16_t* np; int64_t n; int num_conds;
+    float gs, stg, rs; int do_cfg, do_stg, do_rescale;
+    float* lat_f32; uint16_t* lat_bf16; float dt; float* ws;
+};
+
+__device__ __forceinline__ float block_atomic_add(float v, float* dst) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, v);
+    return v;
+}
+
+__device__ __forceinline__ void guidance_fetch(const GuidanceP& p, int64_t i, float& unc, float& txt, float& ptb) {
+    // chunk order is (uncond, text, perturbed): pipeline_ltx_video.py:1035-1051
+    int c = 0;
+    unc = txt = ptb = 0.f;
+    if (p.do_cfg) unc = bf2f(p.np[(int64_t)(c++) * p.n + i]);
+    txt = bf2f(p.np[(int64_t)(c++) * p.n + i]);
+    if (p.do_stg) ptb = bf2f(p.np[(int64_t)(c++) * p.n + i]);
+}
+
+__device__ __forceinline__ float guidance_combine(const GuidanceP& p, float unc, float txt, float ptb, float alpha) {
+    float out = txt;
+    if (p.do_cfg && p.gs != 0.f && p.gs != 1.f) {
+        const float u = alpha * unc;
+        out = u + p.gs * (txt - u);
+    }
+    if (p.do_stg) out = out + p.stg * (txt - ptb);
+    return out;
+}
+
+__global__ void guidance_reduce1(GuidanceP p) {
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
+        float u, t, q;
+        guidance_fetch(p, i, u, t, q);
+        a0 += t * u; a1 += u * u; a2 += t; a3 += t * t;
+    }
+    block_atomic_add(a0, p.ws + 0); block_atomic_add(a1, p.ws + 1);
+    block_atomic_add(a2, p.ws + 2); block_atomic_add(a3, p.ws + 3);
+}
+
+__global__ void guidance_reduce2(GuidanceP p) {
+    const float alpha = p.ws[0] / (p.ws[1] + 1e-8f);
+    float a4 = 0, a5 = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
+        float u, t, q;
+        guidance_fetch(p, i, u, t, q);
+        const float o = guidance_combine(p, u, t, q, alpha);
+        a4 += o; a5 += o * o;
+    }
+    block_atomic_add(a4, p.ws + 4); block_atomic_add(a5, p.ws + 5);
+}
+
+__global__ void guidance_apply(GuidanceP p) {
+    const float alpha = p.ws[0] / (p.ws[1] + 1e-8f);
+    float factor = 1.f;
+    if (p.do_stg && p.do_rescale && p.stg > 0.f) {
+        const float n = (float)p.n;
+        const float var_t = fmaxf((p.ws[3] - p.ws[2] * p.ws[2] / n) / (n - 1.f), 0.f);   // torch .std(): unbiased
+        const float var_o = fmaxf((p.ws[5] - p.ws[4] * p.ws[4] / n) / (n - 1.f), 0.f);
+        factor = p.rs * (sqrtf(var_t) / sqrtf(var_o)) + (1.f - p.rs);
+    }
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
+        float u, t, q;
+        guidance_fetch(p, i, u, t, q);
+        // the reference holds noise_pred in bf16 after the guidance arithmetic; the Euler
+        // update itself runs in the latents' dtype (rf.py:375)
+        const float o = guidance_combine(p, u, t, q, alpha) * factor;
+        if (p.lat_f32) p.lat_f32[i] = p.lat_f32[i] - p.dt * o;
+        else p.lat_bf16[i] = f2bf(bf2f(p.lat_bf16[i]) - p.dt * o);
+    }
+}
+
+}  // namespace ltxmi
+
+using namespace ltxmi;
+
+extern "C" int ltxmi_silu_bf16(const void* x, void* y, int64_t n, void* stream) {
+    LTXMI_REQUIRE(x && y, LTXMI_ERR_INVALID_ARG, "ltxmi_silu_bf16: NULL argument");
+    LTXMI_REQUIRE(n > 0 && n % 8 == 0, LTXMI_ERR_UNSUPPORTED, "ltxmi_silu_bf16: n=%lld must be a positive multiple of 8", (long long)n);
+    hipLaunchKernelGGL(silu_kernel, dim3(pw_grid(n / 8)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, n / 8);
+    return check_launch("ltxmi_silu_bf16");
+}
+
+extern "C" int ltxmi_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream) {
+    LTXMI_REQUIRE(a && b && y, LTXMI_ERR_INVALID_ARG, "ltxmi_add_bf16: NULL argument");
+    LTXMI_REQUIRE(n > 0 && n % 8 == 0, LTXMI_ERR_UNSUPPORTED, "ltxmi_add_bf16: n=%lld must be a positive multiple of 8", (long long)n);
+    hipLaunchKernelGGL(add_kernel, dim3(pw_grid(n / 8)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)a, (const uint16_t*)b, (uint16_t*)y, n / 8);
+    return check_launch("ltxmi_add_bf16");
+}
+
+extern "C" int ltxmi_timestep_embedding_bf16(const float* t, void* out, int32_t n, int32_t dim, void* stream) {
+    LTXMI_REQUIRE(t && out, LTXMI_ERR_INVALID_ARG, "ltxmi_timestep_embedding_bf16: NULL argument");
+    LTXMI_REQUIRE(n > 0 && dim > 0 && dim % 2 == 0, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_timestep_embedding_bf16: n=%d dim=%d (dim must be even)", n, dim);
+    const int total = n * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t,
+                       (uint16_t*)out, n, dim);
+    return check_launch("ltxmi_timestep_embedding_bf16");
+}
+
+extern "C" int ltxmi_stg_blend_bf16(void* a, int64_t lda, const void* v, int64_t ldv, const float* m, int32_t B,
+                                    int32_t L, int32_t D, void* stream) {
+    LTXMI_REQUIRE(a && v && m, LTXMI_ERR_INVALID_ARG, "ltxmi_stg_blend_bf16: NULL argument");
+    LTXMI_REQUIRE(B > 0 && L > 0 && D > 0, LTXMI_ERR_INVALID_ARG, "ltxmi_stg_blend_bf16: non-positive size");
+    LTXMI_REQUIRE(D % 8 == 0 && lda % 8 == 0 && ldv % 8 == 0, LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_stg_blend_bf16: D and strides must be multiples of 8");
+    const int64_t total = (int64_t)B * L * (D / 8);
+    hipLaunchKernelGGL(stg_blend_kernel, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream, (uint16_t*)a,
+                       lda, (const uint16_t*)v, ldv, m, L, D, total);
+    return check_launch("ltxmi_stg_blend_bf16");
+}
+
+extern "C" int ltxmi_ncdhw_to_ndhwc_bf16(const void* z, void* y, int32_t B, int32_t C, int32_t T, int32_t H,
+                                         int32_t W, const float* std, const float* mean, void* stream) {
+    LTXMI_REQUIRE(z && y, LTXMI_ERR_INVALID_ARG, "ltxmi_ncdhw_to_ndhwc_bf16: NULL argument");
+    LTXMI_REQUIRE((std == nullptr) == (mean == nullptr), LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_ncdhw_to_ndhwc_bf16: std and mean must both be given or both be NULL");
+    LTXMI_REQUIRE(B > 0 && C > 0 && T > 0 && H > 0 && W > 0, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_ncdhw_to_ndhwc_bf16: non-positive size");
+    const int64_t thw = (int64_t)T * H * W, total = (int64_t)B * C * thw;
+    hipLaunchKernelGGL(ncdhw_to_ndhwc_kernel, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)z, (uint16_t*)y, C, thw, total, std, mean);
+    return check_launch("ltxmi_ncdhw_to_ndhwc_bf16");
+}
+
+extern "C" int ltxmi_unpatchify_to_ncdhw_bf16(const void* x, void* y, int32_t B, int32_t T, int32_t H, int32_t W,
+                                              int32_t C_out, int32_t patch, void* stream) {
+    LTXMI_REQUIRE(x && y, LTXMI_ERR_INVALID_ARG, "ltxmi_unpatchify_to_ncdhw_bf16: NULL argument");
+    LTXMI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C_out > 0 && patch > 0, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_unpatchify_to_ncdhw_bf16: non-positive size");
+    const int64_t total = (int64_t)B * C_out * T * H * patch * W * patch;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, T, H, W, C_out, patch, total);
+    return check_launch("ltxmi_unpatchify_to_ncdhw_bf16");
+}
+
+extern "C" int ltxmi_guidance_step_bf16(const void* noise_pred, int64_t n, int32_t num_conds, float guidance_scale,
+                                        float stg_scale, float rescaling_scale, int32_t do_cfg, int32_t do_stg,
+                                        int32_t do_rescale, void* latents, int32_t latents_bf16, float dt,
+                                        float* workspace, void* stream) {
+    LTXMI_REQUIRE(noise_pred && latents && workspace, LTXMI_ERR_INVALID_ARG, "ltxmi_guidance_step_bf16: NULL argument");
+    LTXMI_REQUIRE(n > 1, LTXMI_ERR_INVALID_ARG, "ltxmi_guidance_step_bf16: n must be > 1");
+    LTXMI_REQUIRE(num_conds == 1 + (do_cfg ? 1 : 0) + (do_stg ? 1 : 0), LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_guidance_step_bf16: num_conds=%d inconsistent with do_cfg=%d do_stg=%d", num_conds, do_cfg, do_stg);
+    hipStream_t s = (hipStream_t)stream;
+    GuidanceP p;
+    p.np = (const uint16_t*)noise_pred; p.n = n; p.num_conds = num_conds;
+    p.gs = guidance_scale; p.stg = stg_scale; p.rs = rescaling_scale;
+    p.do_cfg = do_cfg; p.do_stg = do_stg; p.do_rescale = do_rescale;
+    p.lat_f32 = latents_bf16 ? nullptr : (float*)latents;
+    p.lat_bf16 = latents_bf16 ? (uint16_t*)latents : nullptr;
+    p.dt = dt; p.ws = workspace;
+    if (hipMemsetAsync(workspace, 0, 8 * sizeof(float), s) != hipSuccess) {
+        set_error("ltxmi_guidance_step_bf16: hipMemsetAsync failed");
+        return LTXMI_ERR_LAUNCH;
+    }
+    const unsigned g = pw_grid(n);
+    hipLaunchKernelGGL(guidance_reduce1, dim3(g), dim3(PW_THREADS), 0, s, p);
+    hipLaunchKernelGGL(guidance_reduce2, dim3(g), dim3(PW_THREADS), 0, s, p);
+    hipLaunchKernelGGL(guidance_apply, dim3(g), dim3(PW_THREADS), 0, s, p);
+    return check_launch("ltxmi_guidance_step_bf16");
+}

@@ -1,0 +1,313 @@
+// rowops.hip -- HBM-bound row kernels of the DiT and VAE paths.
+//
+// All of them are "one wave per row": a row of D channels is read once as 16-byte chunks
+// (lane l takes chunks l, l+64, ...: 1 KiB coalesced per wave-instruction), reduced with
+// a 6-step wave butterfly (no LDS, no barrier), transformed in registers and written once.
+// Algorithmic traffic = one read + one write of the activation (+ the small tables).
+#include "common.h"
+
+namespace ltxmi {
+
+constexpr int ROWS_PER_WG = 4;  // 4 waves, one row each
+
+struct Chunk {
+    float v[8];
+};
+__device__ __forceinline__ Chunk load_chunk(const uint16_t* p) {
+    const u32x4 w = *(const u32x4*)p;
+    Chunk c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        c.v[2 * i] = bf_lo(w[i]);
+        c.v[2 * i + 1] = bf_hi(w[i]);
+    }
+    return c;
+}
+__device__ __forceinline__ void store_chunk(uint16_t* p, const Chunk& c) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16(c.v[2 * i], c.v[2 * i + 1]);
+    *(u32x4*)p = w;
+}
+
+// ------------------------------------------------------------------ norm + AdaLN modulate
+template <int NCH, bool LAYER>
+__global__ __launch_bounds__(256) void norm_modulate_kernel(
+    const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y, int64_t ldy, int rows, int D,
+    float eps, const uint16_t* __restrict__ sc_tab, const uint16_t* __restrict__ sc_temb,
+    const uint16_t* __restrict__ sh_tab, const uint16_t* __restrict__ sh_temb, int64_t temb_ld,
+    int rows_per_group) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = D >> 3;
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    Chunk c[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            c[j] = load_chunk(xr + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1 += c[j].v[e];
+                s2 += c[j].v[e] * c[j].v[e];
+            }
+        }
+    }
+    s2 = wave_sum(s2);
+    float mean = 0.f, rstd;
+    if (LAYER) {
+        s1 = wave_sum(s1);
+        mean = s1 / D;
+        rstd = rsqrtf(fmaxf(s2 / D - mean * mean, 0.f) + eps);
+    } else {
+        rstd = rsqrtf(s2 / D + eps);
+    }
+    const int64_t g = (int64_t)(row / rows_per_group) * temb_ld;
+    uint16_t* yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            const Chunk a = load_chunk(sc_tab + ch * 8), a2 = load_chunk(sc_temb + g + ch * 8);
+            const Chunk b = load_chunk(sh_tab + ch * 8), b2 = load_chunk(sh_temb + g + ch * 8);
+            Chunk o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o.v[e] = (c[j].v[e] - mean) * rstd * (1.0f + a.v[e] + a2.v[e]) + (b.v[e] + b2.v[e]);
+            store_chunk(yr + ch * 8, o);
+        }
+    }
+}
+
+// ------------------------------------------------- q/k RMSNorm(weight) + interleaved RoPE
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(uint16_t* __restrict__ x, int64_t ldx, int rows, int D,
+                                                           const uint16_t* __restrict__ w, float eps,
+                                                           const uint16_t* __restrict__ cs,
+                                                           const uint16_t* __restrict__ sn, int64_t ld_tab,
+                                                           int rope_period) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = D >> 3;
+    uint16_t* xr = x + (int64_t)row * ldx;
+    Chunk c[NCH];
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            c[j] = load_chunk(xr + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s2 += c[j].v[e] * c[j].v[e];
+        }
+    }
+    s2 = wave_sum(s2);
+    const float rstd = rsqrtf(s2 / D + eps);
+    const int64_t trow = cs ? (int64_t)(row % rope_period) * ld_tab : 0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            const Chunk wt = load_chunk(w + ch * 8);
+            Chunk o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] = c[j].v[e] * rstd * wt.v[e];
+            if (cs) {
+                const Chunk co = load_chunk(cs + trow + ch * 8), si = load_chunk(sn + trow + ch * 8);
+                Chunk r2;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    r2.v[e] = o.v[e] * co.v[e] - o.v[e + 1] * si.v[e];
+                    r2.v[e + 1] = o.v[e + 1] * co.v[e + 1] + o.v[e] * si.v[e + 1];
+                }
+                o = r2;
+            }
+            store_chunk(xr + ch * 8, o);
+        }
+    }
+}
+
+// --------------------------------------- PixelNorm -> (1+scale) x + shift -> SiLU (NDHWC rows)
+template <int NCH>
+__global__ __launch_bounds__(256) void pixelnorm_ada_silu_kernel(const uint16_t* __restrict__ x,
+                                                                 uint16_t* __restrict__ y, int64_t rows, int C,
+                                                                 int64_t rows_per_batch,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, int apply_silu,
+                                                                 float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C >> 3;
+    const uint16_t* xr = x + row * C;
+    Chunk c[NCH];
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            c[j] = load_chunk(xr + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s2 += c[j].v[e] * c[j].v[e];
+        }
+    }
+    s2 = wave_sum(s2);
+    const float rstd = rsqrtf(s2 / C + eps);
+    const int64_t bofs = (row / rows_per_batch) * C;
+    uint16_t* yr = y + row * C;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            Chunk o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = c[j].v[e] * rstd;
+                if (scale) v = v * (1.0f + scale[bofs + ch * 8 + e]) + shift[bofs + ch * 8 + e];
+                o.v[e] = apply_silu ? silu_f(v) : v;
+            }
+            store_chunk(yr + ch * 8, o);
+        }
+    }
+}
+
+// ----------------------------------------------------- channel LayerNorm with affine (norm3)
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_affine_kernel(const uint16_t* __restrict__ x,
+                                                               uint16_t* __restrict__ y, int64_t rows, int C,
+                                                               const uint16_t* __restrict__ gamma,
+                                                               const uint16_t* __restrict__ beta, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C >> 3;
+    const uint16_t* xr = x + row * C;
+    Chunk c[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            c[j] = load_chunk(xr + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1 += c[j].v[e];
+                s2 += c[j].v[e] * c[j].v[e];
+            }
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float mean = s1 / C;
+    const float rstd = rsqrtf(fmaxf(s2 / C - mean * mean, 0.f) + eps);
+    uint16_t* yr = y + row * C;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            const Chunk gm = load_chunk(gamma + ch * 8), bt = load_chunk(beta + ch * 8);
+            Chunk o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.v[e] = (c[j].v[e] - mean) * rstd * gm.v[e] + bt.v[e];
+            store_chunk(yr + ch * 8, o);
+        }
+    }
+}
+
+static inline int nch_for(int D) { return D <= 512 ? 1 : (D <= 2048 ? 4 : 16); }
+
+}  // namespace ltxmi
+
+using namespace ltxmi;
+
+#define DISPATCH_NCH(D, CALL)                  \
+    switch (nch_for(D)) {                      \
+        case 1: { constexpr int NCH = 1; CALL; } break;   \
+        case 4: { constexpr int NCH = 4; CALL; } break;   \
+        default: { constexpr int NCH = 16; CALL; } break; \
+    }
+
+extern "C" int ltxmi_norm_modulate_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t D,
+                                        float eps, int32_t kind, const void* scale_table, const void* scale_temb,
+                                        const void* shift_table, const void* shift_temb, int64_t temb_ld,
+                                        int32_t rows_per_group, void* stream) {
+    LTXMI_REQUIRE(x && y && scale_table && scale_temb && shift_table && shift_temb, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_norm_modulate_bf16: NULL argument");
+    LTXMI_REQUIRE(rows > 0 && D > 0 && rows_per_group > 0, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_norm_modulate_bf16: non-positive size rows=%d D=%d", rows, D);
+    LTXMI_REQUIRE(D % 8 == 0 && D <= 8192 && ldx % 8 == 0 && ldy % 8 == 0 && temb_ld % 8 == 0, LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_norm_modulate_bf16: D=%d must be a multiple of 8 and <= 8192 (strides % 8 == 0)", D);
+    LTXMI_REQUIRE(kind == LTXMI_NORM_RMS || kind == LTXMI_NORM_LAYER, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_norm_modulate_bf16: bad kind %d", kind);
+    const int grid = (rows + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    hipStream_t s = (hipStream_t)stream;
+#define CALLK(L)                                                                                            \
+    hipLaunchKernelGGL((norm_modulate_kernel<NCH, L>), dim3(grid), dim3(256), 0, s, (const uint16_t*)x, ldx, \
+                       (uint16_t*)y, ldy, rows, D, eps, (const uint16_t*)scale_table,                       \
+                       (const uint16_t*)scale_temb, (const uint16_t*)shift_table, (const uint16_t*)shift_temb, \
+                       temb_ld, rows_per_group)
+    if (kind == LTXMI_NORM_LAYER) {
+        DISPATCH_NCH(D, CALLK(true))
+    } else {
+        DISPATCH_NCH(D, CALLK(false))
+    }
+#undef CALLK
+    return check_launch("ltxmi_norm_modulate_bf16");
+}
+
+extern "C" int ltxmi_rmsnorm_rope_bf16(void* x, int64_t ldx, int32_t rows, int32_t D, const void* weight, float eps,
+                                       const void* cos_tab, const void* sin_tab, int64_t ld_tab,
+                                       int32_t rope_period, void* stream) {
+    LTXMI_REQUIRE(x && weight, LTXMI_ERR_INVALID_ARG, "ltxmi_rmsnorm_rope_bf16: NULL argument");
+    LTXMI_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr), LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_rmsnorm_rope_bf16: cos and sin must both be given or both be NULL");
+    LTXMI_REQUIRE(rows > 0 && D > 0, LTXMI_ERR_INVALID_ARG, "ltxmi_rmsnorm_rope_bf16: non-positive size");
+    LTXMI_REQUIRE(D % 8 == 0 && D <= 8192 && ldx % 8 == 0, LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_rmsnorm_rope_bf16: D=%d must be a multiple of 8 and <= 8192", D);
+    if (cos_tab) LTXMI_REQUIRE(rope_period > 0 && ld_tab % 8 == 0 && ld_tab >= D, LTXMI_ERR_INVALID_ARG,
+                               "ltxmi_rmsnorm_rope_bf16: bad rope table geometry");
+    const int grid = (rows + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_rope_kernel<NCH>), dim3(grid), dim3(256), 0, s, (uint16_t*)x, ldx,
+                                       rows, D, (const uint16_t*)weight, eps, (const uint16_t*)cos_tab,
+                                       (const uint16_t*)sin_tab, ld_tab, rope_period > 0 ? rope_period : 1))
+    return check_launch("ltxmi_rmsnorm_rope_bf16");
+}
+
+extern "C" int ltxmi_pixelnorm_ada_silu_bf16(const void* x, void* y, int64_t rows, int32_t C,
+                                             int64_t rows_per_batch, const float* scale, const float* shift,
+                                             int32_t apply_silu, float eps, void* stream) {
+    LTXMI_REQUIRE(x && y, LTXMI_ERR_INVALID_ARG, "ltxmi_pixelnorm_ada_silu_bf16: NULL argument");
+    LTXMI_REQUIRE((scale == nullptr) == (shift == nullptr), LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_pixelnorm_ada_silu_bf16: scale and shift must both be given or both be NULL");
+    LTXMI_REQUIRE(rows > 0 && C > 0 && rows_per_batch > 0, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_pixelnorm_ada_silu_bf16: non-positive size");
+    LTXMI_REQUIRE(C % 8 == 0 && C <= 8192, LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_pixelnorm_ada_silu_bf16: C=%d must be a multiple of 8 and <= 8192", C);
+    const int64_t grid = (rows + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    LTXMI_REQUIRE(grid < (1ll << 31), LTXMI_ERR_UNSUPPORTED, "ltxmi_pixelnorm_ada_silu_bf16: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_NCH(C, hipLaunchKernelGGL((pixelnorm_ada_silu_kernel<NCH>), dim3((unsigned)grid), dim3(256), 0, s,
+                                       (const uint16_t*)x, (uint16_t*)y, rows, C, rows_per_batch, scale, shift,
+                                       apply_silu, eps))
+    return check_launch("ltxmi_pixelnorm_ada_silu_bf16");
+}
+
+extern "C" int ltxmi_layernorm_affine_bf16(const void* x, void* y, int64_t rows, int32_t C, const void* gamma,
+                                           const void* beta, float eps, void* stream) {
+    LTXMI_REQUIRE(x && y && gamma && beta, LTXMI_ERR_INVALID_ARG, "ltxmi_layernorm_affine_bf16: NULL argument");
+    LTXMI_REQUIRE(rows > 0 && C > 0, LTXMI_ERR_INVALID_ARG, "ltxmi_layernorm_affine_bf16: non-positive size");
+    LTXMI_REQUIRE(C % 8 == 0 && C <= 8192, LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_layernorm_affine_bf16: C=%d must be a multiple of 8 and <= 8192", C);
+    const int64_t grid = (rows + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    LTXMI_REQUIRE(grid < (1ll << 31), LTXMI_ERR_UNSUPPORTED, "ltxmi_layernorm_affine_bf16: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_NCH(C, hipLaunchKernelGGL((layernorm_affine_kernel<NCH>), dim3((unsigned)grid), dim3(256), 0, s,
+                                       (const uint16_t*)x, (uint16_t*)y, rows, C, (const uint16_t*)gamma,
+                                       (const uint16_t*)beta, eps))
+    return check_launch("ltxmi_layernorm_affine_bf16");
+}

@@ -1,0 +1,90 @@
+"""ctypes binding of libltxmi.so (include/ltxmi.h).
+
+The library is the ONLY compute path of this package: if it cannot be loaded the
+import fails loudly -- there is no PyTorch/CPU fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libltxmi.so")
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("lda", c_int64), ("W", c_void_p), ("ldw", c_int64), ("bias", c_void_p),
+                ("C", c_void_p), ("ldc", c_int64), ("M", c_int), ("N", c_int), ("K", c_int),
+                ("epilogue", c_int), ("residual", c_void_p), ("ldr", c_int64), ("gate_table", c_void_p),
+                ("gate_temb", c_void_p), ("gate_ld", c_int64), ("rows_per_group", c_int)]
+
+
+class AttnArgs(ctypes.Structure):
+    _fields_ = [("q", c_void_p), ("q_stride_b", c_int64), ("q_stride_l", c_int64),
+                ("k", c_void_p), ("k_stride_b", c_int64), ("k_stride_l", c_int64),
+                ("v", c_void_p), ("v_stride_b", c_int64), ("v_stride_l", c_int64),
+                ("o", c_void_p), ("o_stride_b", c_int64), ("o_stride_l", c_int64),
+                ("key_bias", c_void_p), ("bias_stride_b", c_int64),
+                ("B", c_int), ("H", c_int), ("Lq", c_int), ("Lk", c_int), ("head_dim", c_int),
+                ("softmax_scale", c_float)]
+
+
+class Conv3dArgs(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("y", c_void_p),
+                ("B", c_int), ("T", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
+                ("causal", c_int), ("pad_replicate", c_int), ("d2s", c_int), ("residual", c_void_p),
+                ("res_channels", c_int), ("add", c_void_p)]
+
+
+# name -> (restype, argtypes); mirrors include/ltxmi.h one to one
+SIGNATURES = {
+    "ltxmi_version": (ctypes.c_char_p, []),
+    "ltxmi_last_error": (ctypes.c_char_p, []),
+    "ltxmi_arch": (ctypes.c_char_p, []),
+    "ltxmi_gemm_bf16": (c_int, [ctypes.POINTER(GemmArgs), c_void_p]),
+    "ltxmi_norm_modulate_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_float, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ltxmi_rmsnorm_rope_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p,
+                                        c_int64, c_int, c_void_p]),
+    "ltxmi_attention_fwd_bf16": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
+    "ltxmi_silu_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ltxmi_timestep_embedding_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ltxmi_stg_blend_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ltxmi_conv3d_ndhwc_bf16": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
+    "ltxmi_pixelnorm_ada_silu_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p,
+                                              c_int, c_float, c_void_p]),
+    "ltxmi_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "ltxmi_layernorm_affine_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float,
+                                            c_void_p]),
+    "ltxmi_ncdhw_to_ndhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p]),
+    "ltxmi_unpatchify_to_ncdhw_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                               c_void_p]),
+    "ltxmi_guidance_step_bf16": (c_int, [c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_int, c_int,
+                                         c_void_p, c_int, c_float, c_void_p, c_void_p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"ltxmi: {LIB_PATH} is missing -- build it with `make -C ltx-video-gpupoor_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class LtxmiError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status != 0:
+        raise LtxmiError(f"{what} failed ({status}): {lib.ltxmi_last_error().decode()}")

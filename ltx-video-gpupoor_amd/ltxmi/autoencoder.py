@@ -1,0 +1,484 @@
+"""``CausalVideoAutoencoder`` (decode side) on libltxmi kernels.
+
+Drop-in for the reference's decode path:
+  CausalVideoAutoencoder / from_config     ltx_video/models/autoencoders/causal_video_autoencoder.py:33-177
+  AutoencoderKLWrapper.decode (+tiling)    ltx_video/models/autoencoders/vae.py:193-263, 343-413
+  Decoder / UNetMidBlock3D / ResnetBlock3D / DepthToSpaceUpsample   causal_video_autoencoder.py:560-1258
+  CausalConv3d                             ltx_video/models/autoencoders/causal_conv3d.py
+  vae_decode / un_normalize_latents        ltx_video/models/autoencoders/vae_encode.py:94-165, 239-247
+Same config keys, same parameter names (checkpoint-compatible), same ``decode(z, return_dict,
+target_shape, timestep)`` signature and return convention.
+
+Inside, activations are channels-last (NDHWC) bf16 so that every 3x3x3 convolution is an
+implicit GEMM whose K axis (tap, cin) is contiguous in HBM; the reference's temporal
+replicate-pad ``torch.concatenate`` (causal_conv3d.py:46-57) and spatial padding are folded into
+the kernel's address computation, PixelNorm + AdaLN + SiLU are one pass, and the
+depth-to-space rearranges + residual of DepthToSpaceUpsample are the conv's store pattern.
+The encoder is not part of this round's path.
+"""
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .transformer3d import _CombinedTimestepEmbeddings
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class DecoderOutput:
+    sample: torch.Tensor
+
+
+class _Conv3dParams(nn.Module):
+    """Holds ``weight [Cout,Cin,k,k,k]`` / ``bias`` under the name ``conv`` like nn.Conv3d."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        bound = 1.0 / math.sqrt(cin * k ** 3)
+        self.weight = nn.Parameter((torch.rand(cout, cin, k, k, k) * 2 - 1) * bound)
+        self.bias = nn.Parameter((torch.rand(cout) * 2 - 1) * bound)
+
+
+class CausalConv3d(nn.Module):
+    """causal_conv3d.py:7-63.  Kernel 3, stride 1; time padding by frame replication
+    (2 in front when causal, 1+1 otherwise), spatial padding 1 in ``spatial_padding_mode``."""
+
+    def __init__(self, in_channels, out_channels, kernel_size: int = 3, stride=1, dilation=1, groups=1,
+                 spatial_padding_mode: str = "zeros", **kwargs):
+        super().__init__()
+        if kernel_size != 3 or stride != 1 or dilation != 1 or groups != 1:
+            raise NotImplementedError("ltxmi.CausalConv3d: only 3x3x3 / stride 1 / dense is on this path")
+        if spatial_padding_mode not in ("zeros", "replicate"):
+            raise NotImplementedError(f"spatial_padding_mode {spatial_padding_mode}")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.time_kernel_size = 3
+        self.pad_replicate = spatial_padding_mode == "replicate"
+        self.conv = _Conv3dParams(in_channels, out_channels, 3)
+        self._packed = None
+
+    @property
+    def weight(self):
+        return self.conv.weight
+
+    def packed(self, d2s=False):
+        """[Cout, 27*Cin] tap-major bf16 (+ rows re-ordered (p1 p2 p3, c') for the depth-to-space store)."""
+        key = (self.conv.weight.data_ptr(), d2s)
+        if self._packed is None or self._packed[0] != key:
+            with torch.no_grad():
+                w = self.conv.weight.permute(0, 2, 3, 4, 1).reshape(self.out_channels, -1)
+                b = self.conv.bias
+                if d2s:
+                    cp = self.out_channels // 8
+                    w = w.view(cp, 8, -1).transpose(0, 1).reshape(self.out_channels, -1)
+                    b = b.view(cp, 8).transpose(0, 1).reshape(-1)
+                self._packed = (key, w.contiguous().to(BF16), b.contiguous().to(BF16))
+        return self._packed[1], self._packed[2]
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def forward(self, x, causal: bool = True, d2s=False, residual=None, add=None):
+        """x: NDHWC bf16."""
+        w, b = self.packed(d2s)
+        return ops.conv3d(x, w, b, causal, self.pad_replicate, d2s=d2s, residual=residual, add=add)
+
+
+def make_conv_nd(dims, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, causal=False, spatial_padding_mode="zeros", temporal_padding_mode="zeros"):
+    """conv_nd_factory.py:9-72, the (dims=3, causal=True) branch -- the only one the decoder uses."""
+    if dims != 3 or not causal:
+        raise NotImplementedError("ltxmi.make_conv_nd: only dims=3, causal=True is on this path")
+    return CausalConv3d(in_channels, out_channels, kernel_size, stride=stride, dilation=dilation, groups=groups,
+                        spatial_padding_mode=spatial_padding_mode)
+
+
+class _ChannelLayerNorm(nn.Module):            # causal_video_autoencoder.py:1068-1077, key ``norm``
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim, eps=eps, elementwise_affine=True)
+
+    def forward(self, x):
+        return ops.layernorm_affine(x, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class ResnetBlock3D(nn.Module):
+    """causal_video_autoencoder.py:1080-1258 with norm_layer="pixel_norm", inject_noise=False."""
+
+    def __init__(self, dims, in_channels, out_channels=None, dropout=0.0, groups=32, eps=1e-6,
+                 norm_layer="pixel_norm", inject_noise=False, timestep_conditioning=False,
+                 spatial_padding_mode="zeros"):
+        super().__init__()
+        if norm_layer != "pixel_norm" or inject_noise:
+            raise NotImplementedError("ltxmi.ResnetBlock3D: pixel_norm without noise injection only")
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.conv1 = CausalConv3d(in_channels, out_channels, 3, spatial_padding_mode=spatial_padding_mode)
+        self.conv2 = CausalConv3d(out_channels, out_channels, 3, spatial_padding_mode=spatial_padding_mode)
+        if in_channels != out_channels:
+            self.conv_shortcut = _Conv3dParams(in_channels, out_channels, 1)
+            self.norm3 = _ChannelLayerNorm(in_channels, eps)
+        else:
+            self.conv_shortcut = None
+            self.norm3 = None
+        self.timestep_conditioning = timestep_conditioning
+        if timestep_conditioning:
+            self.scale_shift_table = nn.Parameter(torch.randn(4, in_channels) / in_channels ** 0.5)
+
+    def forward(self, x, causal: bool = True, timestep=None):
+        """x NDHWC; timestep: the mid-block's embedding [B, 4C] (bf16) or None."""
+        B = x.shape[0]
+        sc1 = sh1 = sc2 = sh2 = None
+        if self.timestep_conditioning:
+            assert timestep is not None, "should pass timestep with timestep_conditioning=True"
+            # ada_values = table[None] + timestep.reshape(B, 4, C)  (:1211-1221); [B,4,C] scalars
+            ada = (self.scale_shift_table.float()[None] + timestep.float().reshape(B, 4, -1))
+            sh1, sc1, sh2, sc2 = [t.contiguous() for t in ada.unbind(dim=1)]
+        h = ops.pixelnorm_ada_silu(x, sc1, sh1, apply_silu=True)
+        h = self.conv1(h, causal=causal)
+        h = ops.pixelnorm_ada_silu(h, sc2, sh2, apply_silu=True, out=h)
+        if self.conv_shortcut is not None:
+            s = self.norm3(x)
+            Bx, T, H, W, C = s.shape
+            w1 = self.conv_shortcut.weight.reshape(self.out_channels, C)
+            s = ops.gemm(s.view(-1, C), w1, self.conv_shortcut.bias).view(Bx, T, H, W, self.out_channels)
+        else:
+            s = x
+        return self.conv2(h, causal=causal, add=s)            # conv2 + skip add in one epilogue
+
+
+class UNetMidBlock3D(nn.Module):
+    """causal_video_autoencoder.py:805-973 without attention blocks ("res_x")."""
+
+    def __init__(self, dims, in_channels, dropout=0.0, num_layers=1, resnet_eps=1e-6, resnet_groups=32,
+                 norm_layer="pixel_norm", inject_noise=False, timestep_conditioning=False,
+                 attention_head_dim=-1, spatial_padding_mode="zeros"):
+        super().__init__()
+        if attention_head_dim > 0:
+            raise NotImplementedError("ltxmi.UNetMidBlock3D: attn_res_x blocks are not on this path")
+        self.timestep_conditioning = timestep_conditioning
+        if timestep_conditioning:
+            self.time_embedder = _CombinedTimestepEmbeddings(in_channels * 4)
+        self.res_blocks = nn.ModuleList([
+            ResnetBlock3D(dims, in_channels, in_channels, eps=resnet_eps, norm_layer=norm_layer,
+                          inject_noise=inject_noise, timestep_conditioning=timestep_conditioning,
+                          spatial_padding_mode=spatial_padding_mode) for _ in range(num_layers)])
+
+    def forward(self, x, causal: bool = True, timestep=None):
+        temb = None
+        if self.timestep_conditioning:
+            assert timestep is not None, "should pass timestep with timestep_conditioning=True"
+            temb = self.time_embedder(timestep.flatten().float())          # [B, 4C]
+        for blk in self.res_blocks:
+            x = blk(x, causal=causal, timestep=temb)
+        return x
+
+
+class DepthToSpaceUpsample(nn.Module):
+    """causal_video_autoencoder.py:1023-1065 for stride (2,2,2)."""
+
+    def __init__(self, dims, in_channels, stride, residual=False, out_channels_reduction_factor=1,
+                 spatial_padding_mode="zeros"):
+        super().__init__()
+        if tuple(stride) != (2, 2, 2):
+            raise NotImplementedError("ltxmi.DepthToSpaceUpsample: only compress_all (2,2,2) is on this path")
+        self.stride = tuple(stride)
+        self.out_channels = 8 * in_channels // out_channels_reduction_factor
+        self.conv = CausalConv3d(in_channels, self.out_channels, 3, spatial_padding_mode=spatial_padding_mode)
+        self.residual = residual
+        self.out_channels_reduction_factor = out_channels_reduction_factor
+
+    def forward(self, x, causal: bool = True):
+        return self.conv(x, causal=causal, d2s=True, residual=x if self.residual else None)
+
+
+class Decoder(nn.Module):
+    """causal_video_autoencoder.py:560-802."""
+
+    def __init__(self, dims, in_channels=3, out_channels=3, blocks=(("res_x", 1),), base_channels=128,
+                 layers_per_block=2, norm_num_groups=32, patch_size=1, norm_layer="group_norm", causal=True,
+                 timestep_conditioning=False, spatial_padding_mode="zeros"):
+        super().__init__()
+        if dims != 3 or norm_layer != "pixel_norm":
+            raise NotImplementedError("ltxmi.Decoder: dims=3 with pixel_norm only")
+        self.patch_size = patch_size
+        self.out_channels_rgb = out_channels
+        out_channels = out_channels * patch_size ** 2
+        self.causal = causal
+        self.blocks_desc = blocks
+        ch = base_channels
+        for name, params in reversed(list(blocks)):
+            params = params if isinstance(params, dict) else {}
+            if name == "res_x_y":
+                ch *= params.get("multiplier", 2)
+            if name == "compress_all":
+                ch *= params.get("multiplier", 1)
+        self.conv_in = make_conv_nd(dims, in_channels, ch, 3, 1, 1, causal=True,
+                                    spatial_padding_mode=spatial_padding_mode)
+        self.up_blocks = nn.ModuleList([])
+        for name, params in reversed(list(blocks)):
+            cin = ch
+            if isinstance(params, int):
+                params = {"num_layers": params}
+            if name == "res_x":
+                blk = UNetMidBlock3D(dims, cin, num_layers=params["num_layers"], resnet_eps=1e-6,
+                                     norm_layer=norm_layer, inject_noise=params.get("inject_noise", False),
+                                     timestep_conditioning=timestep_conditioning,
+                                     spatial_padding_mode=spatial_padding_mode)
+            elif name == "res_x_y":
+                ch = ch // params.get("multiplier", 2)
+                blk = ResnetBlock3D(dims, cin, ch, eps=1e-6, norm_layer=norm_layer,
+                                    inject_noise=params.get("inject_noise", False), timestep_conditioning=False,
+                                    spatial_padding_mode=spatial_padding_mode)
+            elif name == "compress_all":
+                ch = ch // params.get("multiplier", 1)
+                blk = DepthToSpaceUpsample(dims, cin, (2, 2, 2), residual=params.get("residual", False),
+                                           out_channels_reduction_factor=params.get("multiplier", 1),
+                                           spatial_padding_mode=spatial_padding_mode)
+            else:
+                raise NotImplementedError(f"ltxmi.Decoder: block '{name}' is not on this path")
+            self.up_blocks.append(blk)
+        self.conv_out = make_conv_nd(dims, ch, out_channels, 3, padding=1, causal=True,
+                                     spatial_padding_mode=spatial_padding_mode)
+        self.timestep_conditioning = timestep_conditioning
+        if timestep_conditioning:
+            self.timestep_scale_multiplier = nn.Parameter(torch.tensor(1000.0, dtype=torch.float32))
+            self.last_time_embedder = _CombinedTimestepEmbeddings(ch * 2)
+            self.last_scale_shift_table = nn.Parameter(torch.randn(2, ch) / ch ** 0.5)
+
+    def forward(self, sample, target_shape, timestep: Optional[torch.Tensor] = None):
+        """sample: NDHWC bf16 latents (already un-normalised).  Returns pixels NCDHW bf16."""
+        assert target_shape is not None, "target_shape must be provided"
+        B = sample.shape[0]
+        x = self.conv_in(sample, causal=self.causal)
+        scaled_t = None
+        if self.timestep_conditioning:
+            assert timestep is not None, "should pass timestep with timestep_conditioning=True"
+            scaled_t = timestep.to(torch.float32) * self.timestep_scale_multiplier.float()
+        for blk in self.up_blocks:
+            if self.timestep_conditioning and isinstance(blk, UNetMidBlock3D):
+                x = blk(x, causal=self.causal, timestep=scaled_t)
+            else:
+                x = blk(x, causal=self.causal)
+        sc = sh = None
+        if self.timestep_conditioning:
+            emb = self.last_time_embedder(scaled_t.flatten())                    # [B, 2C]
+            ada = self.last_scale_shift_table.float()[None] + emb.float().reshape(B, 2, -1)
+            sh, sc = [t.contiguous() for t in ada.unbind(dim=1)]
+        x = ops.pixelnorm_ada_silu(x, sc, sh, apply_silu=True, out=x)
+        x = self.conv_out(x, causal=self.causal)
+        return ops.unpatchify_to_ncdhw(x, self.out_channels_rgb, self.patch_size)
+
+
+class _Stats(nn.Module):
+    pass
+
+
+class CausalVideoAutoencoder(nn.Module):
+    def __init__(self, decoder: Decoder, latent_channels=128, dims=3, config=None):
+        super().__init__()
+        self.decoder = decoder
+        self.dims = dims
+        self._config = dict(config or {})
+        self.per_channel_statistics = _Stats()
+        self.per_channel_statistics.register_buffer("std-of-means", torch.ones(latent_channels))
+        self.per_channel_statistics.register_buffer("mean-of-means", torch.zeros(latent_channels))
+        self.use_z_tiling = False
+        self.use_hw_tiling = False
+        self.z_sample_size = 1
+        self.set_tiling_params(sample_size=512, overlap_factor=0.25)
+
+    # ---- construction ------------------------------------------------------------------
+    @staticmethod
+    def from_config(config):                                            # causal_video_autoencoder.py:123-177
+        assert config["_class_name"] == "CausalVideoAutoencoder", "config must have _class_name=CausalVideoAutoencoder"
+        dims = tuple(config["dims"]) if isinstance(config["dims"], list) else config["dims"]
+        if config.get("use_quant_conv", True):
+            raise NotImplementedError("use_quant_conv=True is not on this path (LTX-Video VAEs use False)")
+        if config.get("normalize_latent_channels", False):
+            raise NotImplementedError("normalize_latent_channels is not on this path")
+        decoder = Decoder(dims=dims, in_channels=config["latent_channels"], out_channels=config.get("out_channels", 3),
+                          blocks=config.get("decoder_blocks", config.get("blocks")),
+                          patch_size=config.get("patch_size", 1), norm_layer=config.get("norm_layer", "group_norm"),
+                          causal=config.get("causal_decoder", False),
+                          timestep_conditioning=config.get("timestep_conditioning", False),
+                          base_channels=config.get("decoder_base_channels", 128),
+                          spatial_padding_mode=config.get("spatial_padding_mode", "zeros"))
+        return CausalVideoAutoencoder(decoder, latent_channels=config["latent_channels"], dims=dims, config=config)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):   # :248-298
+        if any(k.startswith("vae.") for k in state_dict.keys()):
+            state_dict = {k.replace("vae.", ""): v for k, v in state_dict.items() if k.startswith("vae.")}
+        remap = {".resnets.": ".res_blocks.", "downsamplers.0": "downsample", "upsamplers.0": "upsample"}
+        out = {}
+        for k, v in state_dict.items():
+            for a, b in remap.items():
+                k = k.replace(a, b)
+            if k.startswith("encoder."):
+                continue                                   # decode-only path
+            out[k] = v
+        return super().load_state_dict(out, strict=strict, assign=assign)
+
+    @property
+    def std_of_means(self):
+        return getattr(self.per_channel_statistics, "std-of-means")
+
+    @property
+    def mean_of_means(self):
+        return getattr(self.per_channel_statistics, "mean-of-means")
+
+    @property
+    def dtype(self):
+        return self.decoder.conv_in.conv.weight.dtype
+
+    @property
+    def device(self):
+        return self.decoder.conv_in.conv.weight.device
+
+    @property
+    def spatial_downscale_factor(self):                                 # :207-225 (decoder blocks mirror the encoder's)
+        n = len([b for b in self.decoder.blocks_desc if b[0] in ("compress_space", "compress_all")])
+        return 2 ** n * self.decoder.patch_size
+
+    @property
+    def temporal_downscale_factor(self):                                # :227-241
+        return 2 ** len([b for b in self.decoder.blocks_desc if b[0] in ("compress_time", "compress_all")])
+
+    # ---- tiling knobs (vae.py:91-154) --------------------------------------------------
+    @staticmethod
+    def get_VAE_tile_size(vae_config, device_mem_capacity, mixed_precision):     # vae.py:91-115
+        z_tile = 4
+        if vae_config == 0:
+            if mixed_precision:
+                device_mem_capacity = device_mem_capacity / 1.5
+            use = 1 if device_mem_capacity >= 24000 else (2 if device_mem_capacity >= 8000 else 3)
+        else:
+            use = vae_config
+        return (z_tile, 0 if use == 1 else (512 if use == 2 else 256))
+
+    def set_tiling_params(self, sample_size: int = 512, overlap_factor: float = 0.25):
+        self.tile_sample_min_size = sample_size
+        self.tile_latent_min_size = int(sample_size / 32)
+        self.tile_overlap_factor = overlap_factor
+
+    def enable_z_tiling(self, z_sample_size: int = 4):
+        self.use_z_tiling = z_sample_size > 1
+        self.z_sample_size = z_sample_size
+        assert z_sample_size % 4 == 0 or z_sample_size == 1, \
+            f"z_sample_size must be a multiple of 4 or 1. Got {z_sample_size}."
+
+    def disable_z_tiling(self):
+        self.use_z_tiling = False
+
+    def enable_hw_tiling(self):
+        self.use_hw_tiling = True
+
+    def disable_hw_tiling(self):
+        self.use_hw_tiling = False
+
+    # ---- decode ------------------------------------------------------------------------
+    def _decode(self, z, target_shape=None, timestep=None, stats=None):          # vae.py:343-355
+        std, mean = stats if stats is not None else (None, None)
+        x = ops.ncdhw_to_ndhwc(z.to(BF16), std, mean)
+        return self.decoder(x, target_shape=target_shape, timestep=timestep)
+
+    @staticmethod
+    def _blend(a, b, extent, dim):
+        """blend_z / blend_v / blend_h (vae.py:193-221): linear cross-fade of the overlap, written
+        into ``b``.  One fused lerp over the overlap instead of the reference's per-slice loop."""
+        extent = min(a.shape[dim], b.shape[dim], extent)
+        if extent <= 0:
+            return b
+        w = (torch.arange(extent, device=b.device, dtype=torch.float32) / extent)
+        shape = [1] * b.dim()
+        shape[dim] = extent
+        w = w.view(shape)
+        sa = a.narrow(dim, a.shape[dim] - extent, extent).float()
+        sb = b.narrow(dim, 0, extent)
+        sb.copy_((sa * (1 - w) + sb.float() * w).to(b.dtype))
+        return b
+
+    def _hw_tiled_decode(self, z, target_shape, timestep=None, stats=None):      # vae.py:223-263
+        overlap_size = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
+        blend_extent = int(self.tile_sample_min_size * self.tile_overlap_factor)
+        row_limit = self.tile_sample_min_size - blend_extent
+        rows = []
+        for i in range(0, z.shape[3], overlap_size):
+            row = []
+            for j in range(0, z.shape[4], overlap_size):
+                tile = z[:, :, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size]
+                row.append(self._decode(tile, target_shape=target_shape, timestep=timestep, stats=stats))
+            rows.append(row)
+        result_rows = []
+        for i, row in enumerate(rows):
+            result_row = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self._blend(rows[i - 1][j], tile, blend_extent, 3)
+                if j > 0:
+                    tile = self._blend(row[j - 1], tile, blend_extent, 4)
+                result_row.append(tile[:, :, :, :row_limit, :row_limit])
+            result_rows.append(torch.cat(result_row, dim=4))
+        return torch.cat(result_rows, dim=3)
+
+    def decode(self, z, return_dict: bool = True, target_shape=None, timestep: Optional[torch.Tensor] = None,
+               _stats=None):
+        """vae.py:357-413.  With z-tiling the tiles are kept on the device (the reference's
+        ``.to(float16).cpu()`` per tile at :388 was a VRAM workaround); the result is fp16 as there."""
+        assert target_shape is not None, "target_shape must be provided for decoding"
+
+        def dec(t):
+            if self.use_hw_tiling:
+                return self._hw_tiled_decode(t, target_shape, timestep, _stats)
+            return self._decode(t, target_shape=target_shape, timestep=timestep, stats=_stats)
+
+        if self.use_z_tiling and z.shape[2] > (self.z_sample_size + 1) > 1:
+            tl = self.z_sample_size
+            ts = tl * 8
+            overlap_size = int(tl * 0.75)
+            blend_extent = int(ts * 0.25)
+            t_limit = ts - blend_extent
+            row = []
+            for i in range(0, z.shape[2], overlap_size):
+                d = dec(z[:, :, i:i + tl + 1])
+                if i > 0:
+                    d = d[:, :, 1:]
+                row.append(d.to(torch.float16))
+            result = []
+            for i, tile in enumerate(row):
+                if i > 0:
+                    tile = self._blend(row[i - 1], tile, blend_extent, 2)
+                    result.append(tile[:, :, :t_limit])
+                else:
+                    result.append(tile[:, :, :t_limit + 1])
+            decoded = torch.cat(result, dim=2)
+        else:
+            decoded = dec(z)
+        if not return_dict:
+            return (decoded,)
+        return DecoderOutput(sample=decoded)
+
+
+def vae_decode(latents, vae: CausalVideoAutoencoder, is_video: bool = True, split_size: int = 1,
+               vae_per_channel_normalize=False, timestep=None):
+    """vae_encode.py:94-165: un-normalise (per-channel std/mean, fused into the layout kernel)
+    and decode.  latents [B,C,F,H,W]."""
+    if split_size != 1:
+        raise NotImplementedError("split_size > 1 is not on this path")
+    *_, fl, hl, wl = latents.shape
+    ts, ss = vae.temporal_downscale_factor, vae.spatial_downscale_factor
+    stats = None
+    if vae_per_channel_normalize:
+        stats = (vae.std_of_means.float().contiguous(), vae.mean_of_means.float().contiguous())
+    return vae.decode(latents.to(vae.dtype), return_dict=False,
+                      target_shape=(1, 3, fl * ts if is_video else 1, hl * ss, wl * ss),
+                      timestep=timestep, _stats=stats)[0]

@@ -1,0 +1,292 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/ltxmi.h).
+
+PyTorch is plumbing only here: it owns the device allocations and the stream; every
+FLOP of the hot path runs in libltxmi.so.  All wrappers launch on
+``torch.cuda.current_stream()`` and never synchronise.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+BF16 = torch.bfloat16
+
+EPI_NONE, EPI_GELU_TANH, EPI_SILU, EPI_GATE_RESIDUAL = 0, 1, 2, 3
+NORM_RMS, NORM_LAYER = 0, 1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- optional per-launch timing (bench.py): HIP events recorded on the launch stream around
+# the launches whose key is being watched; nothing is recorded (or allocated) otherwise.
+_watch = None
+_events = {}
+
+
+def watch_launches(keys):
+    """keys: iterable of ("gemm", M, N, K, epilogue) / ("attention", B, H, Lq, Lk, dh) tuples, or None."""
+    global _watch
+    _watch = set(keys) if keys else None
+    _events.clear()
+
+
+def launch_times_ms():
+    """{key: [ms, ...]} for the watched launches (call after a stream/device synchronize)."""
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in _events.items()}
+
+
+def _prof_begin(key):
+    if _watch is None or key not in _watch:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return key, e0, e1
+
+
+def _prof_end(tok):
+    if tok is not None:
+        tok[2].record()
+        _events.setdefault(tok[0], []).append((tok[1], tok[2]))
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk_bf16(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if t.dtype != BF16 or not t.is_cuda:
+            raise TypeError(f"ltxmi: expected a CUDA bfloat16 tensor, got {t.dtype} on {t.device}")
+
+
+def _rows(t):
+    """View [..., K] with contiguous last dim as (rows, ld)."""
+    if t.stride(-1) != 1:
+        raise ValueError("ltxmi: innermost dimension must be contiguous")
+    t2 = t.reshape(-1, t.shape[-1]) if t.is_contiguous() else t
+    if t2.dim() != 2:
+        raise ValueError("ltxmi: expected a 2-D tensor or a contiguous N-D tensor")
+    return t2, t2.shape[0], t2.stride(0)
+
+
+def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, gate_table=None, gate_temb=None,
+         rows_per_group=1):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  ``a``/``out``/``residual`` may be row-strided 2-D views.
+    gate_temb: 2-D view [groups, N] (row stride = gate_ld)."""
+    _chk_bf16(a, w, bias, out, residual, gate_table, gate_temb)
+    a2, M, lda = _rows(a)
+    N, K = w.shape
+    if a2.shape[1] != K:
+        raise ValueError(f"ltxmi.gemm: a is [{M},{a2.shape[1]}] but w is [{N},{K}]")
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    o2, Mo, ldc = _rows(out)
+    if Mo != M or o2.shape[1] != N:
+        raise ValueError("ltxmi.gemm: bad out shape")
+    args = _lib.GemmArgs()
+    args.A, args.lda = a2.data_ptr(), lda
+    args.W, args.ldw = w.data_ptr(), w.stride(0)
+    args.bias = bias.data_ptr() if bias is not None else None
+    args.C, args.ldc = o2.data_ptr(), ldc
+    args.M, args.N, args.K = M, N, K
+    args.epilogue = epilogue
+    if residual is not None:
+        r2, Mr, ldr = _rows(residual)
+        args.residual, args.ldr = r2.data_ptr(), ldr
+    if gate_table is not None:
+        args.gate_table = gate_table.data_ptr()
+        args.gate_temb = gate_temb.data_ptr()
+        args.gate_ld = gate_temb.stride(0) if gate_temb.dim() == 2 else 0
+    args.rows_per_group = rows_per_group
+    tok = _prof_begin(("gemm", M, N, K, epilogue))
+    check(lib.ltxmi_gemm_bf16(ctypes.byref(args), _stream()), "ltxmi_gemm_bf16")
+    _prof_end(tok)
+    return out
+
+
+def norm_modulate(x, out, eps, kind, scale_table, scale_temb, shift_table, shift_temb, rows_per_group):
+    """out = norm(x) * (1 + scale_table + scale_temb[g]) + shift_table + shift_temb[g].
+    scale_temb/shift_temb: 2-D views [groups, D] sharing one row stride."""
+    _chk_bf16(x, out, scale_table, scale_temb, shift_table, shift_temb)
+    x2, rows, ldx = _rows(x)
+    o2, _, ldy = _rows(out)
+    D = x2.shape[1]
+    if scale_temb.stride(0) != shift_temb.stride(0):
+        raise ValueError("ltxmi.norm_modulate: scale/shift tables must share a row stride")
+    check(lib.ltxmi_norm_modulate_bf16(_ptr(x2), ldx, _ptr(o2), ldy, rows, D, eps, kind,
+                                       _ptr(scale_table), _ptr(scale_temb), _ptr(shift_table), _ptr(shift_temb),
+                                       scale_temb.stride(0), rows_per_group, _stream()),
+          "ltxmi_norm_modulate_bf16")
+    return out
+
+
+def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, rope_period=0):
+    """In place: x = rope(rmsnorm(x) * weight).  x: 2-D row-strided view [rows, D];
+    cos/sin: [period, D] tables (row r uses row r % period) or None."""
+    _chk_bf16(x, weight, cos, sin)
+    x2, rows, ldx = _rows(x)
+    D = x2.shape[1]
+    ld_tab = 0
+    if cos is not None:
+        if cos.dim() != 2 or cos.shape != sin.shape or cos.stride(0) != sin.stride(0):
+            raise ValueError("ltxmi.rmsnorm_rope_: cos/sin must be matching 2-D tables")
+        ld_tab = cos.stride(0)
+        rope_period = rope_period or cos.shape[0]
+    check(lib.ltxmi_rmsnorm_rope_bf16(_ptr(x2), ldx, rows, D, _ptr(weight), eps, _ptr(cos), _ptr(sin), ld_tab,
+                                      rope_period, _stream()), "ltxmi_rmsnorm_rope_bf16")
+    return x
+
+
+def attention(q, k, v, out=None, key_bias=None, softmax_scale=None):
+    """q [B,Lq,H,dh], k/v [B,Lk,H,dh] (NHD; batch and token strides free, (H,dh) contiguous).
+    key_bias: fp32 [B,Lk] additive (broadcast over heads and queries)."""
+    _chk_bf16(q, k, v, out)
+    B, Lq, H, dh = q.shape
+    Lk = k.shape[1]
+    for t in (q, k, v):
+        if t.stride(3) != 1 or t.stride(2) != dh:
+            raise ValueError("ltxmi.attention: (heads, head_dim) must be contiguous")
+    if out is None:
+        out = torch.empty((B, Lq, H, dh), dtype=BF16, device=q.device)
+    a = _lib.AttnArgs()
+    a.q, a.q_stride_b, a.q_stride_l = q.data_ptr(), q.stride(0), q.stride(1)
+    a.k, a.k_stride_b, a.k_stride_l = k.data_ptr(), k.stride(0), k.stride(1)
+    a.v, a.v_stride_b, a.v_stride_l = v.data_ptr(), v.stride(0), v.stride(1)
+    a.o, a.o_stride_b, a.o_stride_l = out.data_ptr(), out.stride(0), out.stride(1)
+    if key_bias is not None:
+        if key_bias.dtype != torch.float32 or key_bias.shape != (B, Lk) or key_bias.stride(1) != 1:
+            raise ValueError("ltxmi.attention: key_bias must be fp32 [B, Lk]")
+        a.key_bias, a.bias_stride_b = key_bias.data_ptr(), key_bias.stride(0)
+    a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, Lk, dh
+    a.softmax_scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(dh)
+    tok = _prof_begin(("attention", B, H, Lq, Lk, dh))
+    check(lib.ltxmi_attention_fwd_bf16(ctypes.byref(a), _stream()), "ltxmi_attention_fwd_bf16")
+    _prof_end(tok)
+    return out
+
+
+def silu(x, out=None):
+    _chk_bf16(x, out)
+    out = torch.empty_like(x) if out is None else out
+    check(lib.ltxmi_silu_bf16(_ptr(x), _ptr(out), x.numel(), _stream()), "ltxmi_silu_bf16")
+    return out
+
+
+def add(a, b, out=None):
+    _chk_bf16(a, b, out)
+    out = torch.empty_like(a) if out is None else out
+    check(lib.ltxmi_add_bf16(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "ltxmi_add_bf16")
+    return out
+
+
+def timestep_embedding(t_f32, dim=256):
+    """t_f32: fp32 [n] (already multiplied by timestep_scale_multiplier) -> bf16 [n, dim]."""
+    if t_f32.dtype != torch.float32 or not t_f32.is_cuda or not t_f32.is_contiguous():
+        raise TypeError("ltxmi.timestep_embedding: expected a contiguous CUDA fp32 vector")
+    out = torch.empty((t_f32.numel(), dim), dtype=BF16, device=t_f32.device)
+    check(lib.ltxmi_timestep_embedding_bf16(_ptr(t_f32), _ptr(out), t_f32.numel(), dim, _stream()),
+          "ltxmi_timestep_embedding_bf16")
+    return out
+
+
+def stg_blend_(a, v, m_f32):
+    """a [B,L,D] (rows contiguous over (B,L)), v row-strided view with the same rows; a = a*m + v*(1-m)."""
+    _chk_bf16(a, v)
+    B, L, D = a.shape
+    a2, _, lda = _rows(a)
+    v2 = v.reshape(B * L, D) if v.is_contiguous() else v
+    if v2.dim() == 3:
+        if v2.stride(0) != L * v2.stride(1):
+            raise ValueError("ltxmi.stg_blend_: v batch stride must equal L * row stride")
+        ldv = v2.stride(1)
+    else:
+        ldv = v2.stride(0)
+    check(lib.ltxmi_stg_blend_bf16(_ptr(a2), lda, _ptr(v2), ldv, _ptr(m_f32), B, L, D, _stream()),
+          "ltxmi_stg_blend_bf16")
+    return a
+
+
+def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, add=None, out=None):
+    """x [B,T,H,W,Cin] NDHWC; w_packed [Cout, 27*Cin] (tap-major; (p1p2p3, c')-major rows when d2s)."""
+    _chk_bf16(x, w_packed, bias, residual, add, out)
+    B, T, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    if not x.is_contiguous() or not w_packed.is_contiguous():
+        raise ValueError("ltxmi.conv3d: x and w must be contiguous")
+    if out is None:
+        if d2s:
+            out = torch.empty((B, 2 * T - 1, 2 * H, 2 * W, Cout // 8), dtype=BF16, device=x.device)
+        else:
+            out = torch.empty((B, T, H, W, Cout), dtype=BF16, device=x.device)
+    a = _lib.Conv3dArgs()
+    a.x, a.w, a.bias, a.y = x.data_ptr(), w_packed.data_ptr(), (bias.data_ptr() if bias is not None else None), out.data_ptr()
+    a.B, a.T, a.H, a.W, a.Cin, a.Cout = B, T, H, W, Cin, Cout
+    a.causal, a.pad_replicate, a.d2s = int(causal), int(pad_replicate), int(d2s)
+    if residual is not None:
+        a.residual, a.res_channels = residual.data_ptr(), residual.shape[-1]
+    if add is not None:
+        if not add.is_contiguous() or add.shape != (B, T, H, W, Cout):
+            raise ValueError("ltxmi.conv3d: `add` must be a contiguous [B,T,H,W,Cout] tensor")
+        a.add = add.data_ptr()
+    check(lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), _stream()), "ltxmi_conv3d_ndhwc_bf16")
+    return out
+
+
+def pixelnorm_ada_silu(x, scale=None, shift=None, apply_silu=True, eps=1e-8, out=None):
+    """x NDHWC [B,T,H,W,C]; scale/shift fp32 [B,C] or None."""
+    _chk_bf16(x, out)
+    B, C = x.shape[0], x.shape[-1]
+    rows = x.numel() // C
+    out = torch.empty_like(x) if out is None else out
+    check(lib.ltxmi_pixelnorm_ada_silu_bf16(_ptr(x), _ptr(out), rows, C, rows // B, _ptr(scale), _ptr(shift),
+                                            int(apply_silu), eps, _stream()), "ltxmi_pixelnorm_ada_silu_bf16")
+    return out
+
+
+def layernorm_affine(x, gamma, beta, eps, out=None):
+    _chk_bf16(x, gamma, beta, out)
+    C = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    check(lib.ltxmi_layernorm_affine_bf16(_ptr(x), _ptr(out), x.numel() // C, C, _ptr(gamma), _ptr(beta), eps,
+                                          _stream()), "ltxmi_layernorm_affine_bf16")
+    return out
+
+
+def ncdhw_to_ndhwc(z, std=None, mean=None):
+    _chk_bf16(z)
+    B, C, T, H, W = z.shape
+    out = torch.empty((B, T, H, W, C), dtype=BF16, device=z.device)
+    check(lib.ltxmi_ncdhw_to_ndhwc_bf16(_ptr(z.contiguous()), _ptr(out), B, C, T, H, W, _ptr(std), _ptr(mean),
+                                        _stream()), "ltxmi_ncdhw_to_ndhwc_bf16")
+    return out
+
+
+def unpatchify_to_ncdhw(x, c_out, patch):
+    _chk_bf16(x)
+    B, T, H, W, _ = x.shape
+    out = torch.empty((B, c_out, T, H * patch, W * patch), dtype=BF16, device=x.device)
+    check(lib.ltxmi_unpatchify_to_ncdhw_bf16(_ptr(x), _ptr(out), B, T, H, W, c_out, patch, _stream()),
+          "ltxmi_unpatchify_to_ncdhw_bf16")
+    return out
+
+
+def guidance_step_(noise_pred, latents, dt, guidance_scale, stg_scale, rescaling_scale, do_cfg, do_stg, do_rescale,
+                   workspace):
+    """noise_pred bf16 [num_conds, N, C] (one sample); latents fp32/bf16 [1, N, C], updated in place."""
+    _chk_bf16(noise_pred)
+    num_conds = noise_pred.shape[0]
+    n = noise_pred[0].numel()
+    is_bf16 = latents.dtype == BF16
+    if not is_bf16 and latents.dtype != torch.float32:
+        raise TypeError("ltxmi.guidance_step_: latents must be fp32 or bf16")
+    check(lib.ltxmi_guidance_step_bf16(_ptr(noise_pred), n, num_conds, guidance_scale, stg_scale, rescaling_scale,
+                                       int(do_cfg), int(do_stg), int(do_rescale), _ptr(latents), int(is_bf16),
+                                       float(dt), _ptr(workspace), _stream()), "ltxmi_guidance_step_bf16")
+    return latents

@@ -1,0 +1,360 @@
+"""Kernel-level parity on a real MI355X: every libltxmi entry point (called through the C ABI
+via ltxmi.ops) against the CPU oracle / an fp32 restatement of the same op on the same seeded
+bf16 inputs.
+
+Tolerances (written once here): outputs are bf16, so a correct kernel differs from the fp32
+truth by one bf16 rounding (relative 2^-9 worst case, ~1.1e-3 rms); accumulation is fp32.
+  REL_L2: relative L2 error of the whole tensor   <= 3e-3
+  MAXABS: max |err| <= 1.6e-2 * max|truth|        (two bf16 ulps at the top of the range)
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REL_L2 = 3e-3
+MAXREL = 1.6e-2
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def check(out, truth, rel_l2=REL_L2, maxrel=MAXREL, what=""):
+    out = out.detach().float().cpu()
+    truth = truth.detach().float().cpu()
+    assert out.shape == truth.shape, (what, out.shape, truth.shape)
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    err = (out - truth).norm() / truth.norm().clamp_min(1e-12)
+    mx = (out - truth).abs().max() / truth.abs().max().clamp_min(1e-12)
+    assert err <= rel_l2, f"{what}: rel L2 {err:.3e} > {rel_l2}"
+    assert mx <= maxrel, f"{what}: max err {mx:.3e} of range > {maxrel}"
+    return float(err)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+# ------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 136, 256), (128, 128, 64), (3, 768, 256),
+                                   (6144, 4096, 256),        # takes the 256x256 / 8-wave tile
+                                   (6145, 4104, 128)])       # 256x256 tile with ragged M and N
+def test_gemm_bias(M, N, K):
+    from ltxmi import ops
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    out = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV))
+    truth = a.float() @ w.float().T + b.float()
+    check(out, truth, what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an ASYMMETRIC W catches a transposed C write (cdna guide, section 3)."""
+    from ltxmi import ops
+    K = 128
+    a = torch.eye(K).to(BF)
+    w = (torch.arange(200 * K).reshape(200, K) % 251).float().sub(125).div(16).to(BF)
+    out = ops.gemm(a.to(DEV), w.to(DEV))
+    assert torch.equal(out.cpu(), w.T.contiguous())
+
+
+@pytest.mark.parametrize("epi", ["gelu", "silu"])
+def test_gemm_activation_epilogues(epi):
+    from ltxmi import ops
+    M, N, K = 515, 384, 192
+    a, w, b = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=K ** -0.5), rnd(N, seed=6)
+    pre = a.float() @ w.float().T + b.float()
+    if epi == "gelu":
+        out = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), epilogue=ops.EPI_GELU_TANH)
+        truth = torch.nn.functional.gelu(pre, approximate="tanh")
+    else:
+        out = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), epilogue=ops.EPI_SILU)
+        truth = torch.nn.functional.silu(pre)
+    check(out, truth, what=epi)
+
+
+def test_gemm_gate_residual_in_place_per_frame():
+    from ltxmi import ops
+    B, F, hw, D, K = 2, 3, 50, 256, 128
+    N = F * hw
+    a, w, b = rnd(B * N, K, seed=7), rnd(D, K, seed=8, scale=K ** -0.5), rnd(D, seed=9)
+    res = rnd(B * N, D, seed=10)
+    table = rnd(6, D, seed=11)
+    temb = rnd(B * F, 6 * D, seed=12)
+    gate = (table[2].float()[None] + temb[:, 2 * D:3 * D].float())               # [B*F, D]
+    truth = res.float() + gate.repeat_interleave(hw, dim=0) * (a.float() @ w.float().T + b.float())
+    r = res.to(DEV).clone()
+    td, ed = table.to(DEV), temb.to(DEV)
+    ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), out=r, epilogue=ops.EPI_GATE_RESIDUAL, residual=r,
+             gate_table=td[2], gate_temb=ed[:, 2 * D:3 * D], rows_per_group=hw)
+    check(r, truth, what="gate_residual")
+    # gate == NULL -> plain residual add
+    r2 = res.to(DEV).clone()
+    ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), out=r2, epilogue=ops.EPI_GATE_RESIDUAL, residual=r2)
+    check(r2, res.float() + a.float() @ w.float().T + b.float(), what="residual")
+
+
+def test_gemm_strided_views():
+    from ltxmi import ops
+    M, K, N = 200, 128, 64
+    big = rnd(M, 3 * K, seed=13)
+    w = rnd(N, K, seed=14, scale=K ** -0.5)
+    out_big = torch.zeros(M, 2 * N, dtype=BF, device=DEV)
+    ops.gemm(big.to(DEV)[:, K:2 * K], w.to(DEV), out=out_big[:, N:])
+    check(out_big[:, N:], big[:, K:2 * K].float() @ w.float().T, what="strided")
+    assert (out_big[:, :N] == 0).all()
+
+
+# -------------------------------------------------------------------------- attention
+def attn_truth(q, k, v, bias=None, scale=None):
+    from oracle import dit
+    mask = None
+    if bias is not None:
+        mask = bias[:, None, None, :].float()          # [B, 1, 1, Lk] in the seam's NHD mask layout
+    if scale is not None:
+        q = (q.float() * (scale * math.sqrt(q.shape[-1]))).float()
+    return dit.sdpa_nhd(q.float(), k.float(), v.float(), mask)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,dh", [(2, 3, 200, 333, 64), (1, 2, 128, 128, 64), (1, 4, 1, 65, 64),
+                                          (2, 2, 257, 64, 128), (1, 3, 77, 200, 128), (1, 2, 640, 1024, 64)])
+def test_attention_self(B, H, Lq, Lk, dh):
+    from ltxmi import ops
+    q, k, v = rnd(B, Lq, H, dh, seed=20), rnd(B, Lk, H, dh, seed=21), rnd(B, Lk, H, dh, seed=22)
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    check(out, attn_truth(q, k, v), what=f"attn {B},{H},{Lq},{Lk},{dh}")
+
+
+@pytest.mark.parametrize("dh", [64, 128])
+def test_attention_key_bias_cross(dh):
+    """T5 cross-attention shape: Lk = 256 with a padded tail masked by a -10000 bias."""
+    from ltxmi import ops
+    B, H, Lq, Lk = 3, 4, 300, 256
+    q, k, v = rnd(B, Lq, H, dh, seed=23), rnd(B, Lk, H, dh, seed=24), rnd(B, Lk, H, dh, seed=25)
+    bias = torch.zeros(B, Lk)
+    bias[0, 96:] = -10000.0
+    bias[1, 10:] = -10000.0
+    bias[2, :] = torch.randn(Lk, generator=torch.Generator().manual_seed(1))     # a soft bias
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), key_bias=bias.to(DEV))
+    check(out, attn_truth(q, k, v, bias), what="cross")
+
+
+def test_attention_fused_qkv_views_and_scale():
+    """q/k/v as strided slices of one [B, N, 3, H, dh] projection buffer, custom softmax scale."""
+    from ltxmi import ops
+    B, N, H, dh = 2, 190, 2, 64
+    qkv = rnd(B, N, 3, H, dh, seed=26).to(DEV)
+    out = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], softmax_scale=0.07)
+    c = qkv.cpu()
+    check(out, attn_truth(c[:, :, 0], c[:, :, 1], c[:, :, 2], scale=0.07), what="fused views")
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running max to jump late in the key sequence (guide rule 26): one key row is
+    strongly aligned with the queries in the LAST tile, so every earlier tile's O/l must be
+    rescaled exactly once."""
+    from ltxmi import ops
+    B, H, Lq, Lk, dh = 1, 2, 96, 448, 64
+    q, k, v = rnd(B, Lq, H, dh, seed=27), rnd(B, Lk, H, dh, seed=28), rnd(B, Lk, H, dh, seed=29)
+    k[:, 400] = q[:, 5] * 3.0          # spike in tile 6 of 7
+    k[:, 70] = q[:, 40] * 2.0          # and an earlier, smaller one
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    check(out, attn_truth(q, k, v), what="rescale branch")
+
+
+def test_pay_attention_seam_contract():
+    from ltxmi import pay_attention
+    B, L, H, dh = 2, 130, 2, 64
+    q, k, v = rnd(B, L, H, dh, seed=30), rnd(B, 77, H, dh, seed=31), rnd(B, 77, H, dh, seed=32)
+    lst = [q.to(DEV), k.to(DEV), v.to(DEV)]
+    out = pay_attention(lst)
+    assert lst == []                                     # the callee clears the list (:185-186)
+    assert out.shape == (B, L, H, dh) and out.dtype == BF
+    check(out, attn_truth(q, k, v), what="seam")
+    with pytest.raises(NotImplementedError):
+        pay_attention([q.to(DEV), k.to(DEV), v.to(DEV)], causal=True)
+    with pytest.raises(TypeError):
+        pay_attention([q.to(DEV).float(), k.to(DEV).float(), v.to(DEV).float()])
+    # k_lens on a single sample: keys beyond k_lens are ignored, queries beyond q_lens are padding
+    out = pay_attention([q[:1].to(DEV), k[:1].to(DEV), v[:1].to(DEV)], k_lens=torch.tensor([50]),
+                        q_lens=torch.tensor([100]))
+    assert out.shape == (1, L, H, dh)
+    check(out[:, :100], attn_truth(q[:1, :100], k[:1, :50], v[:1, :50]), what="k_lens")
+
+
+# -------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("D", [64, 128, 2048, 4096])
+@pytest.mark.parametrize("kind", ["rms", "layer"])
+def test_norm_modulate(D, kind):
+    from ltxmi import ops
+    B, F, hw = 2, 3, 37
+    rows = B * F * hw
+    x = rnd(rows, D, seed=40, scale=2.0)
+    table, temb = rnd(6, D, seed=41, scale=0.3), rnd(B * F, 6 * D, seed=42, scale=0.3)
+    xf = x.float()
+    if kind == "rms":
+        n = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    else:
+        n = torch.nn.functional.layer_norm(xf, (D,), None, None, 1e-6)
+    scale = (table[1].float()[None] + temb[:, D:2 * D].float()).repeat_interleave(hw, 0)
+    shift = (table[0].float()[None] + temb[:, 0:D].float()).repeat_interleave(hw, 0)
+    truth = n * (1 + scale) + shift
+    y = torch.empty(rows, D, dtype=BF, device=DEV)
+    td, ed = table.to(DEV), temb.to(DEV)
+    ops.norm_modulate(x.to(DEV), y, 1e-6, ops.NORM_RMS if kind == "rms" else ops.NORM_LAYER,
+                      td[1], ed[:, D:2 * D], td[0], ed[:, 0:D], hw)
+    check(y, truth, what=f"norm_modulate {kind} {D}")
+
+
+@pytest.mark.parametrize("D", [64, 128, 2048])
+def test_rmsnorm_rope(D):
+    from ltxmi import ops
+    from oracle import dit, leaves
+    B, N = 2, 75
+    buf = rnd(B * N, 3 * D, seed=43)
+    w = (1 + 0.1 * torch.randn(D, generator=torch.Generator().manual_seed(1))).to(BF)
+    cos = torch.cos(torch.randn(N, D, generator=torch.Generator().manual_seed(2))).to(BF)
+    sin = torch.sin(torch.randn(N, D, generator=torch.Generator().manual_seed(3))).to(BF)
+    d = buf.to(DEV).clone()
+    ops.rmsnorm_rope_(d[:, D:2 * D], w.to(DEV), 1e-5, cos.to(DEV), sin.to(DEV), N)
+    x = buf[:, D:2 * D].float().view(B, N, D)
+    nrm = leaves.rms_norm(x, 1e-5, w.float())
+    truth = dit.apply_rotary_emb(nrm, (cos.float()[None], sin.float()[None])).view(B * N, D)
+    check(d[:, D:2 * D], truth, what="rmsnorm+rope")
+    assert torch.equal(d[:, :D].cpu(), buf[:, :D]) and torch.equal(d[:, 2 * D:].cpu(), buf[:, 2 * D:])
+    d2 = buf.to(DEV).clone()
+    ops.rmsnorm_rope_(d2[:, :D], w.to(DEV), 1e-5)                                # no rope (cross-attention)
+    check(d2[:, :D], leaves.rms_norm(buf[:, :D].float(), 1e-5, w.float()), what="rmsnorm only")
+
+
+def test_small_pointwise():
+    from ltxmi import ops
+    from oracle import leaves
+    x = rnd(5, 2048, seed=44, scale=3)
+    check(ops.silu(x.to(DEV)), torch.nn.functional.silu(x.float()), what="silu")
+    y = rnd(5, 2048, seed=45)
+    check(ops.add(x.to(DEV), y.to(DEV)), x.float() + y.float(), what="add")
+    t = torch.tensor([700.0, 50.0, 0.0, 999.0])
+    emb = ops.timestep_embedding(t.to(DEV), 256)
+    check(emb, leaves.get_timestep_embedding(t, 256, flip_sin_to_cos=True, downscale_freq_shift=0.0),
+          rel_l2=4e-3, what="sinusoid")
+    a, v = rnd(3, 20, 128, seed=46), rnd(3, 20, 128, seed=47)
+    m = torch.tensor([1.0, 0.0, 0.25])
+    d = a.to(DEV).clone()
+    ops.stg_blend_(d, v.to(DEV), m.to(DEV))
+    check(d, a.float() * m[:, None, None] + v.float() * (1 - m[:, None, None]), what="stg blend")
+
+
+# ------------------------------------------------------------------------------ VAE
+def ndhwc(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("mode", ["zeros", "replicate"])
+@pytest.mark.parametrize("cin,cout,shape", [(64, 128, (1, 3, 5, 7)), (128, 48, (2, 2, 4, 6)), (64, 264, (1, 1, 3, 3))])
+def test_conv3d(causal, mode, cin, cout, shape):
+    from ltxmi import ops
+    from oracle import vae as ov
+    B, T, H, W = shape
+    x = rnd(B, cin, T, H, W, seed=50)
+    w = rnd(cout, cin, 3, 3, 3, seed=51, scale=(27 * cin) ** -0.5)
+    b = rnd(cout, seed=52)
+    truth = ov.causal_conv3d(x.float(), {"conv.weight": w.float(), "conv.bias": b.float()}, "", causal, mode)
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
+    out = ops.conv3d(ndhwc(x).to(DEV), wp.to(DEV), b.to(DEV), causal, mode == "replicate")
+    check(ncdhw(out.cpu()), truth, what=f"conv3d {causal} {mode} {cin}->{cout}")
+
+
+def test_conv3d_big_tile_and_add():
+    """Enough positions for the 256x256 tile path, plus the fused skip-add epilogue."""
+    from ltxmi import ops
+    from oracle import vae as ov
+    B, T, H, W, cin, cout = 1, 6, 64, 64, 64, 256
+    x = rnd(B, cin, T, H, W, seed=53)
+    w = rnd(cout, cin, 3, 3, 3, seed=54, scale=(27 * cin) ** -0.5)
+    b = rnd(cout, seed=55)
+    skip = rnd(B, cout, T, H, W, seed=56)
+    truth = ov.causal_conv3d(x.float(), {"conv.weight": w.float(), "conv.bias": b.float()}, "", False, "replicate")
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
+    out = ops.conv3d(ndhwc(x).to(DEV), wp.to(DEV), b.to(DEV), False, True, add=ndhwc(skip).to(DEV))
+    check(ncdhw(out.cpu()), truth + skip.float(), what="conv3d big + add")
+
+
+@pytest.mark.parametrize("residual,red", [(True, 2), (False, 1), (True, 1)])
+def test_conv3d_depth_to_space(residual, red):
+    from ltxmi import autoencoder as ae
+    from oracle import vae as ov
+    cin = 64
+    blk = ae.DepthToSpaceUpsample(3, cin, (2, 2, 2), residual=residual, out_channels_reduction_factor=red,
+                                  spatial_padding_mode="replicate").to(BF)
+    sd = {k: v.detach().float() for k, v in blk.state_dict().items()}
+    x = rnd(1, cin, 3, 4, 5, seed=57)
+    truth = ov.depth_to_space_upsample(x.float(), sd, "", dict(stride=(2, 2, 2), residual=residual, reduction=red),
+                                       False, "replicate")
+    out = blk.to(DEV)(ndhwc(x).to(DEV), causal=False)
+    check(ncdhw(out.cpu()), truth, what=f"d2s res={residual} red={red}")
+
+
+@pytest.mark.parametrize("C", [64, 128, 1024])
+def test_pixelnorm_ada_silu_and_layernorm(C):
+    from ltxmi import ops
+    from oracle import vae as ov
+    B, T, H, W = 2, 2, 3, 5
+    x = rnd(B, C, T, H, W, seed=58, scale=2)
+    g = torch.Generator().manual_seed(59)
+    scale, shift = torch.randn(B, C, generator=g) * 0.3, torch.randn(B, C, generator=g) * 0.3
+    xf = x.float()
+    pn = ov.pixel_norm(xf)
+    truth = torch.nn.functional.silu(pn * (1 + scale[:, :, None, None, None]) + shift[:, :, None, None, None])
+    out = ops.pixelnorm_ada_silu(ndhwc(x).to(DEV), scale.to(DEV), shift.to(DEV), apply_silu=True)
+    check(ncdhw(out.cpu()), truth, what="pixelnorm+ada+silu")
+    out = ops.pixelnorm_ada_silu(ndhwc(x).to(DEV), None, None, apply_silu=False)
+    check(ncdhw(out.cpu()), pn, what="pixelnorm")
+    gamma, beta = rnd(C, seed=60), rnd(C, seed=61)
+    out = ops.layernorm_affine(ndhwc(x).to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6)
+    truth = torch.nn.functional.layer_norm(ndhwc(xf), (C,), gamma.float(), beta.float(), 1e-6)
+    check(out, truth, what="layernorm affine")
+
+
+def test_layout_kernels_bit_exact():
+    from ltxmi import ops
+    from oracle import vae as ov
+    z = rnd(2, 16, 3, 4, 5, seed=62)
+    out = ops.ncdhw_to_ndhwc(z.to(DEV))
+    assert torch.equal(out.cpu(), ndhwc(z))
+    std, mean = torch.rand(16) + 0.5, torch.randn(16)
+    out = ops.ncdhw_to_ndhwc(z.to(DEV), std.to(DEV), mean.to(DEV))
+    check(out, ndhwc(z.float() * std.view(1, -1, 1, 1, 1) + mean.view(1, -1, 1, 1, 1)), what="un-normalise")
+    x = rnd(2, 48, 3, 4, 5, seed=63)
+    out = ops.unpatchify_to_ncdhw(ndhwc(x).to(DEV), 3, 4)
+    assert torch.equal(out.cpu(), ov.unpatchify(x, 4, 1))
+
+
+# --------------------------------------------------------------------- guidance + Euler
+@pytest.mark.parametrize("lat_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg,stg,resc", [(3.0, 1.0, 0.7), (1.0, 1.0, 0.7), (3.0, 0.0, 1.0), (3.0, 1.0, 1.0)])
+def test_guidance_step(cfg, stg, resc, lat_dtype):
+    from ltxmi import ops
+    from oracle import sched
+    N, C = 4992, 128
+    do_cfg, do_stg = cfg > 1.0, stg > 0.0
+    gs = cfg if cfg > 1.0 else 0.0
+    nc = 1 + int(do_cfg) + int(do_stg)
+    npred = rnd(nc, N, C, seed=70)
+    lat = torch.randn(1, N, C, generator=torch.Generator().manual_seed(71)).to(lat_dtype)
+    dt = 0.0371
+    truth_v = sched.guidance(npred.float(), nc, gs, stg, resc, do_cfg, do_stg, resc != 1.0)
+    truth = lat.float() - dt * truth_v
+    d = lat.to(DEV).clone()
+    ws = torch.zeros(8, device=DEV)
+    ops.guidance_step_(npred.to(DEV), d, dt, gs, stg, resc, do_cfg, do_stg, resc != 1.0, ws)
+    if lat_dtype == torch.float32:
+        torch.testing.assert_close(d.cpu(), truth, rtol=2e-4, atol=2e-5)
+    else:
+        check(d, truth, what="guidance bf16 latents")
