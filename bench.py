@@ -153,7 +153,10 @@ def cpu_baseline():
     shape for ONE cond, on all host cores; a denoise step is 28 blocks x 3 conds (embeddings,
     output head, guidance are < 1 % and ignored).  Bounded to about 10-30 s."""
     from oracle import dit, sched
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box shows every host core but a 1-GPU job's CPU share is 16 (oversubscribing all 256
+    # logical cores made the oracle 6x slower): use the scheduler affinity, capped at 16
+    ncpu = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(ncpu)
     cfg = dict(dit.default_2b_config(), num_layers=1)
     sd = dit.init_state_dict(cfg, seed=0)
     g = torch.Generator().manual_seed(0)

@@ -108,10 +108,23 @@ struct GuidanceP {
     float* lat_f32; uint16_t* lat_bf16; float dt; float* ws;
 };
 
-__device__ __forceinline__ float block_atomic_add(float v, float* dst) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) atomicAdd(dst, v);
-    return v;
+// block sum through LDS, then ONE float atomic per block and value (256 blocks at most: the
+// per-wave form serialised ~32k same-address atomics, 0.4 ms per call)
+template <int NV>
+__device__ __forceinline__ void block_atomic_add(float (&v)[NV], float* dst) {
+    __shared__ float red[NV][PW_THREADS / 64];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float s = wave_sum(v[i]);
+        if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < PW_THREADS / 64; ++w) s += red[threadIdx.x][w];
+        atomicAdd(dst + threadIdx.x, s);
+    }
 }
 
 __device__ __forceinline__ void guidance_fetch(const GuidanceP& p, int64_t i, float& unc, float& txt, float& ptb) {
@@ -140,8 +153,8 @@ __global__ void guidance_reduce1(GuidanceP p) {
         guidance_fetch(p, i, u, t, q);
         a0 += t * u; a1 += u * u; a2 += t; a3 += t * t;
     }
-    block_atomic_add(a0, p.ws + 0); block_atomic_add(a1, p.ws + 1);
-    block_atomic_add(a2, p.ws + 2); block_atomic_add(a3, p.ws + 3);
+    float acc[4] = {a0, a1, a2, a3};
+    block_atomic_add(acc, p.ws + 0);
 }
 
 __global__ void guidance_reduce2(GuidanceP p) {
@@ -153,7 +166,8 @@ __global__ void guidance_reduce2(GuidanceP p) {
         const float o = guidance_combine(p, u, t, q, alpha);
         a4 += o; a5 += o * o;
     }
-    block_atomic_add(a4, p.ws + 4); block_atomic_add(a5, p.ws + 5);
+    float acc[2] = {a4, a5};
+    block_atomic_add(acc, p.ws + 4);
 }
 
 __global__ void guidance_apply(GuidanceP p) {
@@ -262,7 +276,8 @@ extern "C" int ltxmi_guidance_step_bf16(const void* noise_pred, int64_t n, int32
         set_error("ltxmi_guidance_step_bf16: hipMemsetAsync failed");
         return LTXMI_ERR_LAUNCH;
     }
-    const unsigned g = pw_grid(n);
+    unsigned g = pw_grid(n);
+    if (g > 256) g = 256;
     hipLaunchKernelGGL(guidance_reduce1, dim3(g), dim3(PW_THREADS), 0, s, p);
     hipLaunchKernelGGL(guidance_reduce2, dim3(g), dim3(PW_THREADS), 0, s, p);
     hipLaunchKernelGGL(guidance_apply, dim3(g), dim3(PW_THREADS), 0, s, p);
