@@ -25,6 +25,8 @@
 //
 // Work mapping is XCD-aware: each XCD walks whole (batch, head) pairs, so the 32 CUs that share
 // an L2 stream the same K/V at the same time.
+#include <type_traits>
+
 #include "common.h"
 
 namespace ltxmi {
@@ -44,6 +46,10 @@ constexpr int KV_TILE = 64;
 constexpr int Q_PER_WAVE = 32;
 constexpr int Q_PER_WG = 128;
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef LTXMI_ATTN_QB
+#define LTXMI_ATTN_QB 2
+#endif
+constexpr int ATTN_QB_BIG = LTXMI_ATTN_QB;
 
 template <int DH>
 struct AttnCfg {
@@ -61,9 +67,18 @@ struct AttnCfg {
     }
 };
 
-template <int DH, bool HAS_BIAS>
+#ifndef LTXMI_ATTN_ONES
+#define LTXMI_ATTN_ONES 1      // 1: row sums on the matrix pipe (masked all-ones A operand) instead of v_add
+#endif
+
+// QB = 32-row query blocks per wave (1 or 2).  With QB = 2 a wave owns 64 query rows; the two
+// blocks are independent softmax streams that share every K / V^T fragment read, and the source
+// order  QK(0) QK(1) | softmax(0) | PV(0) | softmax(1) | PV(1)  lets the in-order wave run the
+// VALU softmax of one block underneath the MFMAs of the other.
+template <int DH, bool HAS_BIAS, int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     using C = AttnCfg<DH>;
+    constexpr int QW = Q_PER_WAVE * QB;            // query rows per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -86,12 +101,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const float* biasb = HAS_BIAS ? p.bias + (int64_t)b * p.bias_sb : nullptr;
 
     // ---- Q^T fragments (B operand): lane (r, hh), k-step s holds Q[q][16 s + 8 hh .. +7]
-    const int q_row = qt * Q_PER_WG + wave * Q_PER_WAVE + r;
-    const int q_ld = q_row < p.Lq ? q_row : p.Lq - 1;
-    bf16x8 qf[C::KSTEPS];
+    int q_row[QB];
+    bf16x8 qf[QB][C::KSTEPS];
 #pragma unroll
-    for (int s = 0; s < C::KSTEPS; ++s)
-        qf[s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * hh);
+    for (int i = 0; i < QB; ++i) {
+        q_row[i] = qt * (4 * QW) + wave * QW + 32 * i + r;
+        const int q_ld = q_row[i] < p.Lq ? q_row[i] : p.Lq - 1;
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s)
+            qf[i][s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * hh);
+    }
 
     // ---- staging geometry: thread handles chunks c = tid + 256 i of the [64][DH/8] tile
     int st_key[C::LD_PER_THREAD], st_koff[C::LD_PER_THREAD], st_voff[C::LD_PER_THREAD], st_col[C::LD_PER_THREAD];
@@ -107,13 +126,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     u32x4 kreg[C::LD_PER_THREAD], vreg[C::LD_PER_THREAD];
     float breg = 0.f;
 
-    auto load_tile = [&](int k0) {
+    // per-thread global offsets of its chunks inside a tile (keys beyond Lk are clamped only
+    // when loading the ragged last tile)
+    // (32-bit byte offsets from a wave-uniform tile base -> saddr + voffset loads, no 64-bit VALU math)
+    uint32_t k_goff[C::LD_PER_THREAD], v_goff[C::LD_PER_THREAD];
 #pragma unroll
-        for (int i = 0; i < C::LD_PER_THREAD; ++i) {
-            int key = k0 + st_key[i];
-            key = key < p.Lk ? key : p.Lk - 1;
-            kreg[i] = *(const u32x4*)(kb_ + (int64_t)key * p.k_sl + st_col[i]);
-            vreg[i] = *(const u32x4*)(vb + (int64_t)key * p.v_sl + st_col[i]);
+    for (int i = 0; i < C::LD_PER_THREAD; ++i) {
+        k_goff[i] = (uint32_t)(((int64_t)st_key[i] * p.k_sl + st_col[i]) * 2);
+        v_goff[i] = (uint32_t)(((int64_t)st_key[i] * p.v_sl + st_col[i]) * 2);
+    }
+    auto load_tile = [&](int k0, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        if (!TAIL) {
+            const char* kt = (const char*)(kb_ + (int64_t)k0 * p.k_sl);
+            const char* vt = (const char*)(vb + (int64_t)k0 * p.v_sl);
+#pragma unroll
+            for (int i = 0; i < C::LD_PER_THREAD; ++i) {
+                kreg[i] = *(const u32x4*)(kt + k_goff[i]);
+                vreg[i] = *(const u32x4*)(vt + v_goff[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::LD_PER_THREAD; ++i) {
+                int key = k0 + st_key[i];
+                key = key < p.Lk ? key : p.Lk - 1;
+                kreg[i] = *(const u32x4*)(kb_ + (int64_t)key * p.k_sl + st_col[i]);
+                vreg[i] = *(const u32x4*)(vb + (int64_t)key * p.v_sl + st_col[i]);
+            }
         }
         if (HAS_BIAS && tid < KV_TILE) {
             const int key = k0 + tid;
@@ -140,156 +179,224 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const int g16 = lane >> 4, i16 = lane & 15;
     const int v_rd = C::TILE_BYTES + (4 * (g16 >> 1) + (i16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
 
-    f32x16 oT[C::DBLK];
+    f32x16 oT[QB][C::DBLK];
+    float m_run[QB];           // running max: raw scores (no bias) or scaled+biased log2 domain (bias)
+#if LTXMI_ATTN_ONES
+    // Row sums on the matrix pipe (the VALU is the co-limiting pipe at head_dim 64): the P^T fragment
+    // of the 32x32x16 PV product, re-read as the B operand of a 16x16x32 MFMA, puts query (l & 15)
+    // [+16 for odd 16-lane groups] on the column and this lane's 8 keys in k-group (l >> 4).  With
+    // A = 1 on (row 0, even k-groups) and (row 1, odd k-groups), D[0][n] = sum over the tile's keys of
+    // P[query n] and D[1][n] = the same for query n + 16: lanes 0..15 hold them in registers 0 and 1.
+    // One 16-cycle MFMA per 16 keys replaces 8 v_add per lane; 4 accumulator registers per block.
+    f32x4 lT[QB];
+    bf16x8 ones;
+    {
+        const bool on = ((lane & 15) == 0 && ((lane >> 4) & 1) == 0) || ((lane & 15) == 1 && ((lane >> 4) & 1) == 1);
 #pragma unroll
-    for (int d = 0; d < C::DBLK; ++d)
+        for (int e = 0; e < 8; ++e) ones[e] = on ? (__bf16)1.0f : (__bf16)0.0f;
+    }
+#else
+    float l_run[QB];           // this lane's half of the running row sum
+#endif
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oT[d][e] = 0.f;
-    float m_run = -INFINITY;   // running max: raw scores (no bias) or scaled+biased log2 domain (bias)
-    float l_run = 0.f;         // this lane's share of the running row sum
+    for (int i = 0; i < QB; ++i) {
+        m_run[i] = -INFINITY;
+#if LTXMI_ATTN_ONES
+        lT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+        l_run[i] = 0.f;
+#endif
+#pragma unroll
+        for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oT[i][d][e] = 0.f;
+    }
     const float c = p.scale_log2e;
 
     const int nt = (p.Lk + KV_TILE - 1) / KV_TILE;
-    load_tile(0);
+    const int n_full = p.Lk / KV_TILE;            // tiles with all 64 keys valid
+
+    // One key tile: S^T, online softmax, O^T update.  TAIL (ragged last tile only) masks keys >= Lk.
+    auto tile_body = [&](int t, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        const int cur = t & 1;
+        const char* s = smem + cur * C::STAGE_BYTES;
+
+        // ---------------- S^T = K Q^T, one query block after the other
+        f32x16 sT[QB][2];
+#pragma unroll
+        for (int i = 0; i < QB; ++i)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sT[i][kb][e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < C::KSTEPS; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(s + k_rd[kb] + (((2 * ks + hh) ^ k_sw0) << 4));
+                    sT[i][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[i][ks], sT[i][kb], 0, 0, 0);
+                }
+            }
+
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+            // ---------------- scores -> log2 domain (bias variant), mask, running max
+            if (HAS_BIAS) {
+                const float* bl = (const float*)(s + 2 * C::TILE_BYTES);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 b4 = *(const f32x4*)(bl + 32 * kb + 8 * g + 4 * hh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            sT[i][kb][4 * g + e] = __builtin_fmaf(sT[i][kb][4 * g + e], c, b4[e]);
+                    }
+            }
+            if (TAIL) {
+                const int k0 = t * KV_TILE;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = k0 + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        if (key >= p.Lk) sT[i][kb][e] = -INFINITY;
+                    }
+            }
+            float mt = sT[i][0][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mt = fmaxf(mt, sT[i][0][e]);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sT[i][1][e]);
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+                mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const float m_new = fmaxf(m_run[i], mt);
+            // rescale only when some row's max moved (wave-uniform branch): after the first few
+            // tiles the running max is stable for most tiles and the O-wide multiply is skipped
+            if (__any(m_new != m_run[i])) {
+                asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
+                const float alpha = HAS_BIAS ? fast_exp2(m_run[i] - m_new) : fast_exp2((m_run[i] - m_new) * c);
+#if LTXMI_ATTN_ONES
+                // lane n (< 16) holds the sums of queries n (reg 0) and n + 16 (reg 1)
+                lT[i][0] *= alpha;
+                lT[i][1] *= __shfl(alpha, (lane + 16) & 63, 64);
+#else
+                l_run[i] *= alpha;
+#endif
+#pragma unroll
+                for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oT[i][d][e] *= alpha;
+                m_run[i] = m_new;
+            }
+            const float nmoff = HAS_BIAS ? -m_run[i] : -m_run[i] * c;   // -(max in the exponent's domain)
+
+            // ---------------- P = exp2(x - m), bf16 fragments
+            bf16x8 pf[4];
+#if !LTXMI_ATTN_ONES
+            float lsum = 0.f;
+#endif
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float x = HAS_BIAS ? (sT[i][kb][e] + nmoff) : __builtin_fmaf(sT[i][kb][e], c, nmoff);
+                    sT[i][kb][e] = fast_exp2(x);
+#if !LTXMI_ATTN_ONES
+                    lsum += sT[i][kb][e];
+#endif
+                }
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[2 * kb + h2][e] = (__bf16)sT[i][kb][8 * h2 + e];
+            }
+#if !LTXMI_ATTN_ONES
+            l_run[i] += lsum;
+#endif
+
+            // ---------------- O^T += V^T P^T  (;  l += ones . P^T)
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+#if LTXMI_ATTN_ONES
+                lT[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[sp], lT[i], 0, 0, 0);
+#endif
+#pragma unroll
+                for (int d = 0; d < C::DBLK; ++d) {
+                    const char* base = s + v_rd + (2 * sp * C::DBLK + d) * 512;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(base));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(base + C::DBLK * 512));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
+                    oT[i][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sp], oT[i][d], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    using no_tail = std::integral_constant<bool, false>;
+    using with_tail = std::integral_constant<bool, true>;
+    if (n_full > 0) load_tile(0, no_tail{}); else load_tile(0, with_tail{});
     write_tile(0);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        const char* s = smem + cur * C::STAGE_BYTES;
-        if (t + 1 < nt) load_tile((t + 1) * KV_TILE);
-
-        // ---------------- S^T = K Q^T
-        f32x16 sT[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sT[kb][e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < C::KSTEPS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(s + k_rd[kb] + (((2 * ks + hh) ^ k_sw0) << 4));
-                sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sT[kb], 0, 0, 0);
-            }
+    // full tiles: prefetch t+1 (itself full, or the ragged last one), compute t, stage t+1
+    for (int t = 0; t < n_full; ++t) {
+        const bool has_next = t + 1 < nt;
+        if (has_next) {
+            if (t + 1 < n_full) load_tile((t + 1) * KV_TILE, no_tail{});
+            else load_tile((t + 1) * KV_TILE, with_tail{});
         }
-
-        // ---------------- scores -> log2 domain, mask, running max
-        const int k0 = t * KV_TILE;
-        const bool tail = (k0 + KV_TILE > p.Lk);
-        if (HAS_BIAS) {
-            const float* bl = (const float*)(s + 2 * C::TILE_BYTES);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 b4 = *(const f32x4*)(bl + 32 * kb + 8 * g + 4 * hh);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sT[kb][4 * g + e] = sT[kb][4 * g + e] * c + b4[e];
-                }
-        }
-        if (tail) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = k0 + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    if (key >= p.Lk) sT[kb][e] = -INFINITY;
-                }
-        }
-        float mt = sT[0][0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) mt = fmaxf(mt, sT[0][e]);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sT[1][e]);
-        {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        const float m_new = fmaxf(m_run, mt);
-        float alpha, moff;
-        if (HAS_BIAS) {
-            alpha = fast_exp2(m_run - m_new);
-            moff = m_new;
-        } else {
-            alpha = fast_exp2((m_run - m_new) * c);
-            moff = m_new * c;
-        }
-        m_run = m_new;
-
-        // ---------------- P = exp2(x - m), row sum, bf16 fragments
-        float lsum = 0.f;
-        bf16x8 pf[4];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float x = HAS_BIAS ? (sT[kb][e] - moff) : (sT[kb][e] * c - moff);
-                const float pe = fast_exp2(x);
-                sT[kb][e] = pe;
-                lsum += pe;
-            }
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pf[2 * kb + h2][e] = (__bf16)sT[kb][8 * h2 + e];
-        }
-        l_run = l_run * alpha + lsum;
-#pragma unroll
-        for (int d = 0; d < C::DBLK; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oT[d][e] *= alpha;
-
-        // ---------------- O^T += V^T P^T
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-#pragma unroll
-            for (int d = 0; d < C::DBLK; ++d) {
-                const char* base = s + v_rd + (2 * sp * C::DBLK + d) * 512;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(base));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(base + C::DBLK * 512));
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
-                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, both);
-                oT[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sp], oT[d], 0, 0, 0);
-            }
-        }
-
-        if (t + 1 < nt) write_tile(cur ^ 1);
+        tile_body(t, no_tail{});
+        if (has_next) write_tile((t & 1) ^ 1);
         __syncthreads();
     }
+    if (n_full < nt) tile_body(n_full, with_tail{});      // ragged last tile (nothing left to prefetch)
 
     // ---------------- epilogue: O = O^T / l
-    {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-        l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    const float inv = 1.0f / l_run;
-    if (q_row < p.Lq) {
-        uint16_t* orow = ob + (int64_t)q_row * p.o_sl;
 #pragma unroll
-        for (int d = 0; d < C::DBLK; ++d)
+    for (int i = 0; i < QB; ++i) {
+#if LTXMI_ATTN_ONES
+        // query r's sum sits in lane (r & 15), register (r >> 4)
+        const float l0 = __shfl(lT[i][0], r & 15, 64), l1 = __shfl(lT[i][1], r & 15, 64);
+        const float l = (r & 16) ? l1 : l0;
+#else
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[i]), __float_as_uint(l_run[i]), false, false);
+        const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+#endif
+        const float inv = 1.0f / l;
+        if (q_row[i] < p.Lq) {
+            uint16_t* orow = ob + (int64_t)q_row[i] * p.o_sl;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 w;
-                w[0] = pack_bf16(oT[d][4 * g + 0] * inv, oT[d][4 * g + 1] * inv);
-                w[1] = pack_bf16(oT[d][4 * g + 2] * inv, oT[d][4 * g + 3] * inv);
-                *(u32x2*)(orow + 32 * d + 8 * g + 4 * hh) = w;
-            }
+            for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 w;
+                    w[0] = pack_bf16(oT[i][d][4 * g + 0] * inv, oT[i][d][4 * g + 1] * inv);
+                    w[1] = pack_bf16(oT[i][d][4 * g + 2] * inv, oT[i][d][4 * g + 3] * inv);
+                    *(u32x2*)(orow + 32 * d + 8 * g + 4 * hh) = w;
+                }
+        }
     }
 }
 
-template <int DH, bool HAS_BIAS>
-static int launch(const AttnParams& p, hipStream_t stream) {
+template <int DH, bool HAS_BIAS, int QB>
+static int launch(AttnParams p, hipStream_t stream) {
     using C = AttnCfg<DH>;
-    auto kern = attn_fwd_kernel<DH, HAS_BIAS>;
+    auto kern = attn_fwd_kernel<DH, HAS_BIAS, QB>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         attr_set = true;
     }
-    const int grid = p.B * p.H * p.q_tiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::SMEM, stream, p);
+    const int q_per_wg = Q_PER_WG * QB;
+    p.q_tiles = (p.Lq + q_per_wg - 1) / q_per_wg;
+    const int64_t grid = (int64_t)p.B * p.H * p.q_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C::SMEM, stream, p);
     return check_launch("ltxmi_attention_fwd_bf16");
 }
 
@@ -321,6 +428,13 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     p.scale_log2e = a->softmax_scale * LOG2E;
     p.q_tiles = (a->Lq + Q_PER_WG - 1) / Q_PER_WG;
     hipStream_t s = (hipStream_t)stream;
-    if (a->head_dim == 64) return a->key_bias ? launch<64, true>(p, s) : launch<64, false>(p, s);
-    return a->key_bias ? launch<128, true>(p, s) : launch<128, false>(p, s);
+    // 64 query rows per wave (two blocks sharing each K/V fragment) once there is enough work to
+    // fill the chip with 256-row workgroups; 32 rows per wave otherwise (and always at head_dim 128,
+    // where two blocks of accumulators do not fit the register file at 2 waves per SIMD)
+    const int64_t wg256 = (int64_t)a->B * a->H * ((a->Lq + 255) / 256);
+    if (a->head_dim == 64) {
+        if (wg256 >= 512 && !a->key_bias) return launch<64, false, ATTN_QB_BIG>(p, s);
+        return a->key_bias ? launch<64, true, 1>(p, s) : launch<64, false, 1>(p, s);
+    }
+    return a->key_bias ? launch<128, true, 1>(p, s) : launch<128, false, 1>(p, s);
 }

@@ -118,7 +118,9 @@ def attn_truth(q, k, v, bias=None, scale=None):
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,dh", [(2, 3, 200, 333, 64), (1, 2, 128, 128, 64), (1, 4, 1, 65, 64),
-                                          (2, 2, 257, 64, 128), (1, 3, 77, 200, 128), (1, 2, 640, 1024, 64)])
+                                          (2, 2, 257, 64, 128), (1, 3, 77, 200, 128), (1, 2, 640, 1024, 64),
+                                          (2, 32, 2100, 333, 64),    # enough work for the 64-rows-per-wave path
+                                          (1, 64, 2049, 192, 64)])
 def test_attention_self(B, H, Lq, Lk, dh):
     from ltxmi import ops
     q, k, v = rnd(B, Lq, H, dh, seed=20), rnd(B, Lk, H, dh, seed=21), rnd(B, Lk, H, dh, seed=22)
