@@ -18,8 +18,8 @@
 // address and again on the read (cdna_hip_programming.md rule 21).  With that swizzle the
 // 16-lane ds_read_b128 groups of the 16x16x32 operand map hit 16 distinct 16-byte slots.
 //
-// Pipeline: two LDS stages; the LDS-DMA for K-tile t+1 is issued before the MFMAs of tile
-// t, one __syncthreads() (s_waitcnt vmcnt(0) + s_barrier) per K-tile.
+// Pipeline: two LDS stages, one __syncthreads() per K-tile; the LDS-DMA runs a full K-tile ahead
+// and the MFMA fragments are double-buffered in registers (see the main loop).
 //
 // Block -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous band of M-tiles so
 // the W panel and the A rows they share stay in that XCD's private L2.
@@ -172,29 +172,68 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- main loop.  Two LDS stages, ONE barrier per K-tile, and the fragments double-buffered in
+    // registers so that no MFMA ever waits on an LDS read issued after a barrier:
+    //   phase A: MFMAs on the k-step-0 fragments (already in registers)  ||  ds_read k-step 1
+    //   __syncthreads(): k-step-1 fragments landed, LDS-DMA of tile t+1 landed and visible
+    //   phase B: LDS-DMA of tile t+2 into the stage just drained; MFMAs on k-step 1  ||  ds_read
+    //            k-step 0 of tile t+1
     const int nk = p.K / BK;
     stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+
+    bf16x8 af0[MI], bf0[NI], af1[MI], bf1[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af0[i] = *(const bf16x8*)(smem + a_off[i]);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bf0[j] = *(const bf16x8*)(smem + b_off[j]);
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
         const char* s = smem + cur * STAGE_BYTES;
+        // ---- phase A: the first MFMA row group issues before the k-step-1 reads, so the only LDS
+        // wait in front of an MFMA is for fragments fetched half a K-tile ago
+        constexpr int MI_HEAD = MI > 2 ? 2 : 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            // chunk index + 4*ks: XOR with (row&7) commutes with flipping bit 2
-            bf16x8 af[MI], bfr[NI];
+        for (int i = 0; i < MI_HEAD; ++i)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(s + (a_off[i] ^ (ks << 6)));
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j], af0[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(s + (b_off[j] ^ (ks << 6)));
+        for (int i = 0; i < MI; ++i) af1[i] = *(const bf16x8*)(s + (a_off[i] ^ 64));
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < NI; ++j) bf1[j] = *(const bf16x8*)(s + (b_off[j] ^ 64));
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
+        for (int i = MI_HEAD; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[j], af0[i], acc[i][j], 0, 0, 0);
+        // Keep phase A's MFMAs on this side of the barrier (hipcc otherwise sinks the register-only
+        // MFMAs below it, which puts the ds_read wait back in front of them), and wait for the
+        // LDS-DMA explicitly: across the loop back-edge hipcc's own __syncthreads() lowering was
+        // observed to wait for lgkmcnt only, not for the pending global_load_lds.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase B
+        if (kt + 2 < nk) stage(cur, kt + 2);
+        if (kt + 1 < nk) {
+            const char* sn = smem + (cur ^ 1) * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af0[i] = *(const bf16x8*)(sn + a_off[i]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf0[j] = *(const bf16x8*)(sn + b_off[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j], af1[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- epilogue.  acc[i][j][e]: row m = m0 + wm*WM + i*16 + (lane&15),
