@@ -23,6 +23,10 @@
 //
 // Block -> tile mapping is XCD-aware: the 8 XCDs each get a contiguous band of M-tiles so
 // the W panel and the A rows they share stay in that XCD's private L2.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace ltxmi {
@@ -30,7 +34,7 @@ namespace ltxmi {
 struct GemmParams {
     const uint16_t* A; int64_t lda;
     const uint16_t* W; int64_t ldw;
-    const uint16_t* bias;
+    const uint16_t* bias; int bias_stride;   // never NULL: a zero page with stride 0 stands in for "no bias"
     uint16_t* C; int64_t ldc;
     int M, N, K;
     const uint16_t* R; int64_t ldr;
@@ -48,6 +52,7 @@ struct GemmParams {
 };
 
 constexpr int EPI_D2S = 4;   // internal: conv + pixel-shuffle(2,2,2) scatter (+ residual)
+constexpr int EPI_RESIDUAL = 5;   // internal: GATE_RESIDUAL without a gate (C = R + acc + bias)
 
 // 64 zero bytes: LDS-DMA source for zero-padded taps
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[16];
@@ -238,42 +243,57 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
 
     // ---- epilogue.  acc[i][j][e]: row m = m0 + wm*WM + i*16 + (lane&15),
     //                               col n = n0 + wn*WN + j*16 + (lane>>4)*4 + e
+    // Every load below is unconditional (masked lanes read a clamped address): a runtime-conditional
+    // load makes hipcc branch around it and wait vmcnt(0) per element -- 32 dependent L2 round trips.
     const int erow = lane & 15;
     const int ecol = (lane >> 4) * 4;
+    constexpr bool GATED = (EPI == LTXMI_EPI_GATE_RESIDUAL);
+    constexpr bool RESID = (EPI == LTXMI_EPI_GATE_RESIDUAL || EPI == EPI_RESIDUAL);
+    u32x2 bias_v[NI], gt_v[NI];
+    int ncl[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 16 + ecol;
+        ncl[j] = n < p.N ? n : p.N - 4;
+        bias_v[j] = *(const u32x2*)(p.bias + ncl[j] * p.bias_stride);
+        if (GATED) gt_v[j] = *(const u32x2*)(p.gate_table + ncl[j]);
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * WM + i * 16 + erow;
-        if (m >= p.M) continue;
-        const uint16_t* gate_row = nullptr;
-        if (EPI == LTXMI_EPI_GATE_RESIDUAL && p.gate_table)
-            gate_row = p.gate_temb + (int64_t)(m / p.rows_per_group) * p.gate_ld;
+        const bool m_ok = m < p.M;
+        const int mc = m_ok ? m : p.M - 1;
+        const uint16_t* gate_row = GATED ? p.gate_temb + (int64_t)(mc / p.rows_per_group) * p.gate_ld : nullptr;
+        u32x2 ge_v[NI], rr_v[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (GATED) ge_v[j] = *(const u32x2*)(gate_row + ncl[j]);
+            if (RESID) rr_v[j] = *(const u32x2*)(p.R + (int64_t)mc * p.ldr + ncl[j]);
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = n0 + wn * WN + j * 16 + ecol;
-            if (n >= p.N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.bias) {
-                const u32x2 b = *(const u32x2*)(p.bias + n);
-                v[0] += bf_lo(b[0]); v[1] += bf_hi(b[0]); v[2] += bf_lo(b[1]); v[3] += bf_hi(b[1]);
-            }
+            v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
+            v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
             if (EPI == LTXMI_EPI_GELU_TANH) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
             } else if (EPI == LTXMI_EPI_SILU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-            } else if (EPI == LTXMI_EPI_GATE_RESIDUAL) {
-                if (gate_row) {
-                    const u32x2 gt = *(const u32x2*)(p.gate_table + n);
-                    const u32x2 ge = *(const u32x2*)(gate_row + n);
-                    v[0] *= bf_lo(gt[0]) + bf_lo(ge[0]);
-                    v[1] *= bf_hi(gt[0]) + bf_hi(ge[0]);
-                    v[2] *= bf_lo(gt[1]) + bf_lo(ge[1]);
-                    v[3] *= bf_hi(gt[1]) + bf_hi(ge[1]);
-                }
-                const u32x2 rr = *(const u32x2*)(p.R + (int64_t)m * p.ldr + n);
-                v[0] += bf_lo(rr[0]); v[1] += bf_hi(rr[0]); v[2] += bf_lo(rr[1]); v[3] += bf_hi(rr[1]);
             }
+            if (GATED) {
+                v[0] *= bf_lo(gt_v[j][0]) + bf_lo(ge_v[j][0]);
+                v[1] *= bf_hi(gt_v[j][0]) + bf_hi(ge_v[j][0]);
+                v[2] *= bf_lo(gt_v[j][1]) + bf_lo(ge_v[j][1]);
+                v[3] *= bf_hi(gt_v[j][1]) + bf_hi(ge_v[j][1]);
+            }
+            if (RESID) {
+                v[0] += bf_lo(rr_v[j][0]); v[1] += bf_hi(rr_v[j][0]);
+                v[2] += bf_lo(rr_v[j][1]); v[3] += bf_hi(rr_v[j][1]);
+            }
+            if (!(m_ok && n < p.N)) continue;
             u32x2 o;
             if (EPI == EPI_D2S) {
                 // weight rows are packed (p1 p2 p3)-major: n = pp * C' + c'
@@ -304,6 +324,288 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
     }
 }
 
+// =====================================================================================
+// Persistent variant for the dense (MODE 0) 256x256 tile: one workgroup per CU walks its list of
+// output tiles and treats (tile, k-tile) as ONE stream, so the LDS-DMA pipeline never drains:
+// the loads of the next tile's first two K-tiles are in flight while the current tile's
+// accumulators are converted and stored, the stores drain under the next tile's MFMAs, and there
+// is no per-tile workgroup dispatch.  Per-tile fixed cost measured before this: ~13-15 us per
+// round against ~48 us of main loop at K = 2048.
+//   * epilogue stores are raw buffer stores, unconditionally issued (out-of-range rows/columns get
+//     an out-of-range offset and are dropped by the hardware bounds check), so their COUNT per wave
+//     is the compile-time constant MI*NI: the first barrier after an epilogue waits with
+//     s_waitcnt vmcnt(MI*NI), i.e. for the older LDS-DMA only, not for the stores;
+// =====================================================================================
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent_kernel(GemmParams p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = (BM / 8) / NW;
+    constexpr int B_INSTR = (BN / 8) / NW;
+    constexpr int N_STORES = MI * NI;
+    static_assert(N_STORES <= 63, "vmcnt immediate is 6 bits");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // ---- this workgroup's tiles: the tile ids are cut into 8 contiguous ranges (one per XCD,
+    // blocks b and b+8 share an XCD) and the workgroups of an XCD stride through its range, so
+    // the tiles running concurrently on an XCD are neighbours in the band order
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nwg = gridDim.x, wg = blockIdx.x;
+    const int xcd = wg & 7, lw = wg >> 3;
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int x0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int xcnt = tq + (xcd < tr ? 1 : 0);
+    const int nw_x = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);
+    const int my_n = lw < xcnt ? (xcnt - lw + nw_x - 1) / nw_x : 0;
+    if (my_n == 0) return;
+    constexpr int GN = 8;
+    auto tile_origin = [&](int i, int& m0, int& n0) {
+        const int tile = x0 + lw + i * nw_x;
+        const int band_sz = p.tiles_m * GN;
+        const int band = tile / band_sz, rem = tile % band_sz;
+        const int gn = min(GN, p.tiles_n - band * GN);
+        m0 = (rem / gn) * BM;
+        n0 = (band * GN + rem % gn) * BN;
+    };
+
+    // ---- LDS-DMA source offsets: per-lane 32-bit byte offsets from a wave-uniform tile base
+    const int srow = lane >> 3, sslot = lane & 7;
+    struct Src {
+        const char* abase; const char* bbase;
+        uint32_t aoff[A_INSTR], boff[B_INSTR];
+        int m0, n0;
+    };
+    auto set_tile = [&](int i, Src& t) {
+        tile_origin(i, t.m0, t.n0);
+        t.abase = (const char*)(p.A + (int64_t)t.m0 * p.lda);
+        t.bbase = (const char*)(p.W + (int64_t)t.n0 * p.ldw);
+        const int mlast = p.M - 1 - t.m0, nlast = p.N - 1 - t.n0;
+#pragma unroll
+        for (int j = 0; j < A_INSTR; ++j) {
+            const int row = (wave * A_INSTR + j) * 8 + srow;
+            t.aoff[j] = (uint32_t)(min(row, mlast) * (int)p.lda * 2 + ((sslot ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < B_INSTR; ++j) {
+            const int row = (wave * B_INSTR + j) * 8 + srow;
+            t.boff[j] = (uint32_t)(min(row, nlast) * (int)p.ldw * 2 + ((sslot ^ (row & 7)) << 4));
+        }
+    };
+    auto stage = [&](int buf, const Src& t, int kt) {
+        char* sa = smem + buf * STAGE_BYTES;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < A_INSTR; ++j) glds16(t.abase + t.aoff[j] + kt * (BK * 2), sa + (wave * A_INSTR + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < B_INSTR; ++j) glds16(t.bbase + t.boff[j] + kt * (BK * 2), sb + (wave * B_INSTR + j) * 1024);
+    };
+
+    // fragment (i) of a wave sits 16 rows = 2048 bytes below fragment (i-1) and has the same
+    // (row & 7), so one base offset per operand and k-step plus immediates addresses all of them
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int a_off0 = (wm * WM + frow) * 128 + ((fchunk ^ (frow & 7)) << 4);
+    const int b_off0 = A_BYTES + (wn * WN + frow) * 128 + ((fchunk ^ (frow & 7)) << 4);
+    const int a_off1 = a_off0 ^ 64, b_off1 = b_off0 ^ 64;
+
+    // output / residual through buffer descriptors (hardware bounds check drops masked stores)
+    const uint32_t c_bytes = (uint32_t)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2);
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, c_bytes, 0x00020000);
+    const int erow = lane & 15, ecol = (lane >> 4) * 4;
+
+    f32x4 acc[MI][NI];
+    bf16x8 af0[MI], bf0[NI], af1[MI], bf1[NI];
+
+    constexpr bool GATED = (EPI == LTXMI_EPI_GATE_RESIDUAL);
+    constexpr bool RESID = (EPI == LTXMI_EPI_GATE_RESIDUAL || EPI == EPI_RESIDUAL);
+    // All epilogue loads are unconditional and issued in batches (see the note in the kernel above).
+    auto epilogue = [&](int m0, int n0) {
+        u32x2 bias_v[NI], gt_v[NI];
+        int ncl[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WN + j * 16 + ecol;
+            ncl[j] = n < p.N ? n : p.N - 4;
+            bias_v[j] = *(const u32x2*)(p.bias + ncl[j] * p.bias_stride);
+            if (GATED) gt_v[j] = *(const u32x2*)(p.gate_table + ncl[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * WM + i * 16 + erow;
+            const bool m_ok = m < p.M;
+            const int mc = m_ok ? m : p.M - 1;                    // clamped row for the reads
+            const uint16_t* gate_row = GATED ? p.gate_temb + (int64_t)(mc / p.rows_per_group) * p.gate_ld : nullptr;
+            u32x2 ge_v[NI], rr_v[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                if (GATED) ge_v[j] = *(const u32x2*)(gate_row + ncl[j]);
+                if (RESID) rr_v[j] = *(const u32x2*)(p.R + (int64_t)mc * p.ldr + ncl[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int n = n0 + wn * WN + j * 16 + ecol;
+                const bool ok = m_ok && n < p.N;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
+                v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
+                if (EPI == LTXMI_EPI_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                } else if (EPI == LTXMI_EPI_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                if (GATED) {
+                    v[0] *= bf_lo(gt_v[j][0]) + bf_lo(ge_v[j][0]);
+                    v[1] *= bf_hi(gt_v[j][0]) + bf_hi(ge_v[j][0]);
+                    v[2] *= bf_lo(gt_v[j][1]) + bf_lo(ge_v[j][1]);
+                    v[3] *= bf_hi(gt_v[j][1]) + bf_hi(ge_v[j][1]);
+                }
+                if (RESID) {
+                    v[0] += bf_lo(rr_v[j][0]); v[1] += bf_hi(rr_v[j][0]);
+                    v[2] += bf_lo(rr_v[j][1]); v[3] += bf_hi(rr_v[j][1]);
+                }
+                u32x2 o;
+                o[0] = pack_bf16(v[0], v[1]);
+                o[1] = pack_bf16(v[2], v[3]);
+                const uint32_t off = ok ? (uint32_t)(((int64_t)m * p.ldc + n) * 2) : 0xfffffff0u;
+                __builtin_amdgcn_raw_buffer_store_b64(o, c_rsrc, off, 0, 0);
+            }
+        }
+    };
+
+    const int nk = p.K / BK;                 // >= 2 on this path
+    Src cs;                                 // current tile; the next tile's offsets are rebuilt on
+    set_tile(0, cs);                        // the two occasions they are needed (registers are scarce)
+    stage(0, cs, 0);
+    stage(1, cs, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af0[i] = *(const bf16x8*)(smem + a_off0 + i * 2048);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bf0[j] = *(const bf16x8*)(smem + b_off0 + j * 2048);
+
+    constexpr int MI_HEAD = MI > 2 ? 2 : 1;
+    // phase A of one K-tile: MFMAs on the k-step-0 fragments, k-step-1 fragment reads in between.
+    // FIRST: first K-tile of an output tile, accumulate onto 0 (fresh accumulator values per tile).
+    auto phase_a = [&](const char* s, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+        for (int i = 0; i < MI_HEAD; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    bf0[j], af0[i], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af1[i] = *(const bf16x8*)(s + a_off1 + i * 2048);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf1[j] = *(const bf16x8*)(s + b_off1 + j * 2048);
+#pragma unroll
+        for (int i = MI_HEAD; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    bf0[j], af0[i], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_f0 = [&](const char* sn) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af0[i] = *(const bf16x8*)(sn + a_off0 + i * 2048);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf0[j] = *(const bf16x8*)(sn + b_off0 + j * 2048);
+    };
+    auto mfma_f1 = [&]() {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j], af1[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // barrier between the phases: the LDS-DMA of the NEXT k-tile must have landed
+    auto sync_all = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // phase B of a K-tile that is not the tile's last: refill the drained stage with k-tile (+2) of the
+    // stream (this tile's, or the next tile's first), fetch the next k-step-0 fragments, MFMAs on k-step 1
+    auto phase_b_mid = [&](int cur, int kt, int ti) {
+        if (kt + 2 < nk) {
+            stage(cur, cs, kt + 2);
+        } else if (ti + 1 < my_n) {
+            Src ns;
+            set_tile(ti + 1, ns);
+            stage(cur, ns, kt + 2 - nk);
+        }
+        read_f0(smem + (cur ^ 1) * STAGE_BYTES);
+        mfma_f1();
+    };
+    using first_t = std::integral_constant<bool, true>;
+    using next_t = std::integral_constant<bool, false>;
+
+    int flat = 0;                            // running k-tile count: stage parity
+    for (int ti = 0; ti < my_n; ++ti) {
+        // ---- K-tile 0 (never the last: nk >= 2)
+        {
+            const int cur = flat & 1;
+            phase_a(smem + cur * STAGE_BYTES, first_t{});
+            // right after an epilogue the N_STORES younger buffer stores may still be in flight:
+            // wait for everything older than them (the LDS-DMA) only
+            if (ti > 0) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                sync_all();
+            }
+            phase_b_mid(cur, 0, ti);
+            ++flat;
+        }
+        // ---- middle K-tiles
+        for (int kt = 1; kt < nk - 1; ++kt) {
+            const int cur = flat & 1;
+            phase_a(smem + cur * STAGE_BYTES, next_t{});
+            sync_all();
+            phase_b_mid(cur, kt, ti);
+            ++flat;
+        }
+        // ---- last K-tile, then the epilogue under the next tile's loads
+        {
+            const int cur = flat & 1;
+            phase_a(smem + cur * STAGE_BYTES, next_t{});
+            sync_all();
+            mfma_f1();
+            // next tile's K-tile 1 goes into the stage this K-tile just drained; issued BEFORE the
+            // stores so that vmcnt(N_STORES) at the next barrier covers it
+            if (ti + 1 < my_n) {
+                Src ns;
+                set_tile(ti + 1, ns);
+                stage(cur, ns, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue(cs.m0, cs.n0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ti + 1 < my_n) {
+                set_tile(ti + 1, cs);
+                // k-step-0 fragments of the next tile are fetched only now: holding them across the
+                // epilogue would not fit the register file next to the 128 accumulators
+                read_f0(smem + (cur ^ 1) * STAGE_BYTES);
+            }
+            ++flat;
+        }
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
 static int launch_tile(const GemmParams& p0, int epi, hipStream_t stream, const char* what) {
     GemmParams p = p0;
@@ -328,15 +630,67 @@ static int launch_tile(const GemmParams& p0, int epi, hipStream_t stream, const 
             case LTXMI_EPI_GELU_TANH: LTXMI_GEMM_LAUNCH(LTXMI_EPI_GELU_TANH) break;
             case LTXMI_EPI_SILU: LTXMI_GEMM_LAUNCH(LTXMI_EPI_SILU) break;
             case LTXMI_EPI_GATE_RESIDUAL: LTXMI_GEMM_LAUNCH(LTXMI_EPI_GATE_RESIDUAL) break;
+            case EPI_RESIDUAL: LTXMI_GEMM_LAUNCH(EPI_RESIDUAL) break;
             default: set_error("%s: bad epilogue %d", what, epi); return LTXMI_ERR_INVALID_ARG;
         }
     } else {
         if (epi == EPI_D2S) LTXMI_GEMM_LAUNCH(EPI_D2S)
-        else if (epi == LTXMI_EPI_GATE_RESIDUAL) LTXMI_GEMM_LAUNCH(LTXMI_EPI_GATE_RESIDUAL)
+        else if (epi == EPI_RESIDUAL) LTXMI_GEMM_LAUNCH(EPI_RESIDUAL)
         else LTXMI_GEMM_LAUNCH(LTXMI_EPI_NONE)
     }
 #undef LTXMI_GEMM_LAUNCH
     return check_launch(what);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_persistent(const GemmParams& p0, int epi, hipStream_t stream, const char* what) {
+    GemmParams p = p0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            set_error("%s: cannot query the device", what);
+            return LTXMI_ERR_LAUNCH;
+        }
+        n_cu = prop.multiProcessorCount;
+    }
+    const int grid = ntiles < n_cu ? ntiles : n_cu;      // one 8-wave workgroup per CU (128 KB LDS each)
+    constexpr int threads = WAVES_M * WAVES_N * 64;
+    constexpr int smem = 2 * (BM + BN) * BK * 2;
+#define LTXMI_GEMM_LAUNCH_P(E)                                                                        \
+    {                                                                                                 \
+        auto kern = gemm_bf16_nt_persistent_kernel<BM, BN, WAVES_M, WAVES_N, E>;                      \
+        static bool attr_set = false;                                                                 \
+        if (!attr_set) {                                                                              \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+            attr_set = true;                                                                          \
+        }                                                                                             \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, stream, p);                        \
+    }
+    switch (epi) {
+        case LTXMI_EPI_NONE: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_NONE) break;
+        case LTXMI_EPI_GELU_TANH: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_GELU_TANH) break;
+        case LTXMI_EPI_SILU: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_SILU) break;
+        case LTXMI_EPI_GATE_RESIDUAL: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_GATE_RESIDUAL) break;
+        case EPI_RESIDUAL: LTXMI_GEMM_LAUNCH_P(EPI_RESIDUAL) break;
+        default: set_error("%s: bad epilogue %d", what, epi); return LTXMI_ERR_INVALID_ARG;
+    }
+#undef LTXMI_GEMM_LAUNCH_P
+    return check_launch(what);
+}
+
+// device address of the zero page (stands in for a missing bias with stride 0)
+static const uint16_t* zero_page_ptr() {
+    static const uint16_t* ptr = nullptr;
+    if (!ptr) {
+        void* d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_page)) == hipSuccess) ptr = (const uint16_t*)d;
+    }
+    return ptr;
 }
 
 }  // namespace ltxmi
@@ -366,7 +720,9 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     GemmParams p;
     p.A = (const uint16_t*)a->A; p.lda = a->lda;
     p.W = (const uint16_t*)a->W; p.ldw = a->ldw;
-    p.bias = (const uint16_t*)a->bias;
+    p.bias = a->bias ? (const uint16_t*)a->bias : zero_page_ptr();
+    p.bias_stride = a->bias ? 1 : 0;
+    LTXMI_REQUIRE(p.bias, LTXMI_ERR_LAUNCH, "ltxmi_gemm_bf16: cannot resolve the zero page");
     p.C = (uint16_t*)a->C; p.ldc = a->ldc;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.R = (const uint16_t*)a->residual; p.ldr = a->ldr;
@@ -377,12 +733,20 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     p.tiles_m = p.tiles_n = 0;
     p.cB = p.cT = p.cH = p.cW = p.cCin = 1; p.tpad = 0; p.pad_replicate = 0; p.res = nullptr; p.res_ch = 0;
     hipStream_t s = (hipStream_t)stream;
+    const int epi = (a->epilogue == LTXMI_EPI_GATE_RESIDUAL && !a->gate_table) ? EPI_RESIDUAL : a->epilogue;
     // Tile choice: 256x256 (8 waves) when it still fills the 256 CUs, else 128x128 (4 waves,
     // 2 blocks/CU); skinny problems (adaLN tables, text K/V) take the 128x128 path too.
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-    if (a->M >= 1024 && a->N >= 256 && t256 >= 384)
-        return launch_tile<256, 256, 2, 4, 0>(p, a->epilogue, s, "ltxmi_gemm_bf16");
-    return launch_tile<128, 128, 2, 2, 0>(p, a->epilogue, s, "ltxmi_gemm_bf16");
+    static const int force_tile = getenv("LTXMI_GEMM_TILE") ? atoi(getenv("LTXMI_GEMM_TILE")) : 0;   // tuning knob
+    if (force_tile == 128) return launch_tile<128, 128, 2, 2, 0>(p, epi, s, "ltxmi_gemm_bf16");
+    if (a->M >= 1024 && a->N >= 256 && t256 >= 384) {
+        const bool fits32 = ((int64_t)a->M * a->ldc * 2 < (1ll << 32)) && ((int64_t)256 * a->lda * 2 < (1ll << 31)) &&
+                            ((int64_t)256 * a->ldw * 2 < (1ll << 31));
+        if (a->K >= 128 && fits32 && force_tile != 256)
+            return launch_persistent<256, 256, 2, 4>(p, epi, s, "ltxmi_gemm_bf16");
+        return launch_tile<256, 256, 2, 4, 0>(p, epi, s, "ltxmi_gemm_bf16");
+    }
+    return launch_tile<128, 128, 2, 2, 0>(p, epi, s, "ltxmi_gemm_bf16");
 }
 
 extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream) {
@@ -406,7 +770,9 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
     GemmParams p;
     p.A = (const uint16_t*)a->x; p.lda = a->Cin;
     p.W = (const uint16_t*)a->w; p.ldw = 27ll * a->Cin;
-    p.bias = (const uint16_t*)a->bias;
+    p.bias = a->bias ? (const uint16_t*)a->bias : zero_page_ptr();
+    p.bias_stride = a->bias ? 1 : 0;
+    LTXMI_REQUIRE(p.bias, LTXMI_ERR_LAUNCH, "ltxmi_conv3d_ndhwc_bf16: cannot resolve the zero page");
     p.C = (uint16_t*)a->y; p.ldc = a->Cout;
     p.M = (int)M; p.N = a->Cout; p.K = 27 * a->Cin;
     p.R = nullptr; p.ldr = 0; p.gate_table = nullptr; p.gate_temb = nullptr; p.gate_ld = 0; p.rows_per_group = 1;
@@ -419,7 +785,7 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
     hipStream_t s = (hipStream_t)stream;
     LTXMI_REQUIRE(!(a->d2s && a->add), LTXMI_ERR_INVALID_ARG, "ltxmi_conv3d_ndhwc_bf16: `add` is for the plain store only");
     if (a->add) { p.R = (const uint16_t*)a->add; p.ldr = a->Cout; }
-    const int epi = a->d2s ? EPI_D2S : (a->add ? LTXMI_EPI_GATE_RESIDUAL : LTXMI_EPI_NONE);
+    const int epi = a->d2s ? EPI_D2S : (a->add ? EPI_RESIDUAL : LTXMI_EPI_NONE);
     const long t256 = (long)((M + 255) / 256) * ((a->Cout + 255) / 256);
     if (a->Cout >= 256 && t256 >= 384) return launch_tile<256, 256, 2, 4, 1>(p, epi, s, "ltxmi_conv3d_ndhwc_bf16");
     return launch_tile<128, 128, 2, 2, 1>(p, epi, s, "ltxmi_conv3d_ndhwc_bf16");
