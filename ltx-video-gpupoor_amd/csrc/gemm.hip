@@ -345,7 +345,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int A_INSTR = (BM / 8) / NW;
     constexpr int B_INSTR = (BN / 8) / NW;
-    constexpr int N_STORES = MI * NI;
+    constexpr int N_STORES = (MI / 2) * 4;       // 16-byte buffer stores per wave and tile
+    static_assert(MI % 2 == 0 && WN == 64, "epilogue scratch is a 32 x 64 bf16 chunk per wave");
     static_assert(N_STORES <= 63, "vmcnt immediate is 6 bits");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -425,7 +426,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
 
     constexpr bool GATED = (EPI == LTXMI_EPI_GATE_RESIDUAL);
     constexpr bool RESID = (EPI == LTXMI_EPI_GATE_RESIDUAL || EPI == EPI_RESIDUAL);
-    // All epilogue loads are unconditional and issued in batches (see the note in the kernel above).
+    // Epilogue.  All loads are unconditional and issued in batches (see the note in the kernel
+    // above).  The stores go through a 4 KB per-wave LDS scratch (the 32 KB left beside the two
+    // 64 KB stages): a lane's accumulator fragment is 4 columns of one row, so storing from
+    // registers means 8-byte pieces of 16 different 128-byte lines per instruction; transposed
+    // through LDS every store instruction writes 8 whole 128-byte lines, 16 bytes per lane, and the
+    // instruction count halves (the store tail is issue-bound: cdna guide T21).
+    char* scr = smem + 2 * STAGE_BYTES + wave * 4096;
     auto epilogue = [&](int m0, int n0) {
         u32x2 bias_v[NI], gt_v[NI];
         int ncl[NI];
@@ -437,46 +444,59 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             if (GATED) gt_v[j] = *(const u32x2*)(p.gate_table + ncl[j]);
         }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * WM + i * 16 + erow;
-            const bool m_ok = m < p.M;
-            const int mc = m_ok ? m : p.M - 1;                    // clamped row for the reads
-            const uint16_t* gate_row = GATED ? p.gate_temb + (int64_t)(mc / p.rows_per_group) * p.gate_ld : nullptr;
-            u32x2 ge_v[NI], rr_v[NI];
+        for (int c = 0; c < MI / 2; ++c) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                if (GATED) ge_v[j] = *(const u32x2*)(gate_row + ncl[j]);
-                if (RESID) rr_v[j] = *(const u32x2*)(p.R + (int64_t)mc * p.ldr + ncl[j]);
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * c + ii;
+                const int m = m0 + wm * WM + i * 16 + erow;
+                const int mc = m < p.M ? m : p.M - 1;                 // clamped row for the reads
+                const uint16_t* gate_row = GATED ? p.gate_temb + (int64_t)(mc / p.rows_per_group) * p.gate_ld : nullptr;
+                u32x2 ge_v[NI], rr_v[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if (GATED) ge_v[j] = *(const u32x2*)(gate_row + ncl[j]);
+                    if (RESID) rr_v[j] = *(const u32x2*)(p.R + (int64_t)mc * p.ldr + ncl[j]);
+                }
+                const int row_l = ii * 16 + erow;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
+                    v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
+                    if (EPI == LTXMI_EPI_GELU_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                    } else if (EPI == LTXMI_EPI_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+                    if (GATED) {
+                        v[0] *= bf_lo(gt_v[j][0]) + bf_lo(ge_v[j][0]);
+                        v[1] *= bf_hi(gt_v[j][0]) + bf_hi(ge_v[j][0]);
+                        v[2] *= bf_lo(gt_v[j][1]) + bf_lo(ge_v[j][1]);
+                        v[3] *= bf_hi(gt_v[j][1]) + bf_hi(ge_v[j][1]);
+                    }
+                    if (RESID) {
+                        v[0] += bf_lo(rr_v[j][0]); v[1] += bf_hi(rr_v[j][0]);
+                        v[2] += bf_lo(rr_v[j][1]); v[3] += bf_hi(rr_v[j][1]);
+                    }
+                    u32x2 o;
+                    o[0] = pack_bf16(v[0], v[1]);
+                    o[1] = pack_bf16(v[2], v[3]);
+                    // 8-byte piece (j*4 + lane>>4) of scratch row row_l; 16-byte chunks XOR-swizzled by row
+                    const int chunk = j * 2 + (lane >> 5);
+                    *(u32x2*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4) + ((lane >> 4) & 1) * 8) = o;
+                }
             }
+            // read the 32 x 64 chunk back row-major: lane -> (row l>>3 [+8t], 16-byte chunk l&7)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int n = n0 + wn * WN + j * 16 + ecol;
-                const bool ok = m_ok && n < p.N;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
-                v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
-                if (EPI == LTXMI_EPI_GELU_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-                } else if (EPI == LTXMI_EPI_SILU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                }
-                if (GATED) {
-                    v[0] *= bf_lo(gt_v[j][0]) + bf_lo(ge_v[j][0]);
-                    v[1] *= bf_hi(gt_v[j][0]) + bf_hi(ge_v[j][0]);
-                    v[2] *= bf_lo(gt_v[j][1]) + bf_lo(ge_v[j][1]);
-                    v[3] *= bf_hi(gt_v[j][1]) + bf_hi(ge_v[j][1]);
-                }
-                if (RESID) {
-                    v[0] += bf_lo(rr_v[j][0]); v[1] += bf_hi(rr_v[j][0]);
-                    v[2] += bf_lo(rr_v[j][1]); v[3] += bf_hi(rr_v[j][1]);
-                }
-                u32x2 o;
-                o[0] = pack_bf16(v[0], v[1]);
-                o[1] = pack_bf16(v[2], v[3]);
-                const uint32_t off = ok ? (uint32_t)(((int64_t)m * p.ldc + n) * 2) : 0xfffffff0u;
-                __builtin_amdgcn_raw_buffer_store_b64(o, c_rsrc, off, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                const int row_l = t * 8 + (lane >> 3), chunk = lane & 7;
+                const u32x4 w = *(const u32x4*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4));
+                const int m = m0 + wm * WM + c * 32 + row_l;
+                const int n = n0 + wn * WN + chunk * 8;
+                const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((int64_t)m * p.ldc + n) * 2) : 0xfffffff0u;
+                __builtin_amdgcn_raw_buffer_store_b128(w, c_rsrc, off, 0, 0);
             }
         }
     };
@@ -658,9 +678,9 @@ static int launch_persistent(const GemmParams& p0, int epi, hipStream_t stream, 
         }
         n_cu = prop.multiProcessorCount;
     }
-    const int grid = ntiles < n_cu ? ntiles : n_cu;      // one 8-wave workgroup per CU (128 KB LDS each)
+    const int grid = ntiles < n_cu ? ntiles : n_cu;      // one 8-wave workgroup per CU (all 160 KB of LDS)
     constexpr int threads = WAVES_M * WAVES_N * 64;
-    constexpr int smem = 2 * (BM + BN) * BK * 2;
+    constexpr int smem = 2 * (BM + BN) * BK * 2 + WAVES_M * WAVES_N * 4096;   // 2 stages + epilogue scratch
 #define LTXMI_GEMM_LAUNCH_P(E)                                                                        \
     {                                                                                                 \
         auto kern = gemm_bf16_nt_persistent_kernel<BM, BN, WAVES_M, WAVES_N, E>;                      \
