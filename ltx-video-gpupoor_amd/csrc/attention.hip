@@ -76,9 +76,15 @@ struct AttnCfg {
 // order  QK(0) QK(1) | softmax(0) | PV(0) | softmax(1) | PV(1)  lets the in-order wave run the
 // VALU softmax of one block underneath the MFMAs of the other.
 template <int DH, bool HAS_BIAS, int QB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
     using C = AttnCfg<DH>;
     constexpr int QW = Q_PER_WAVE * QB;            // query rows per wave
+    // FOLD (no key bias): the scale lives in Q and the running max enters the QK^T product itself
+    // through one extra MFMA k-step ([1,1,0..] x [-m_hi,-m_lo,0..]), so the accumulator already
+    // holds x - m and the per-element VALU work is max + exp2 + cvt: no multiply, no subtract.
+    // The VALU issue port is the binding resource of this kernel (PMC: VALU busy 61 % of SIMD
+    // time at 52 % MFMA utilisation), the matrix pipe has the headroom for the extra k-step.
+    constexpr bool FOLD = !HAS_BIAS && DH == 128;   // measured: pays at head_dim 128, not at 64
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -108,8 +114,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         q_row[i] = qt * (4 * QW) + wave * QW + 32 * i + r;
         const int q_ld = q_row[i] < p.Lq ? q_row[i] : p.Lq - 1;
 #pragma unroll
-        for (int s = 0; s < C::KSTEPS; ++s)
+        for (int s = 0; s < C::KSTEPS; ++s) {
             qf[i][s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * hh);
+            if (FOLD) {
+                // fold softmax_scale * log2(e) into Q once (bf16 re-rounding of Q: ~2^-9 relative per
+                // element, averaged over head_dim in the dot product -- below the bf16 rounding of P)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[i][s][e] = (__bf16)((float)qf[i][s][e] * p.scale_log2e);
+            }
+        }
     }
 
     // ---- staging geometry: thread handles chunks c = tid + 256 i of the [64][DH/8] tile
@@ -198,9 +211,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #else
     float l_run[QB];           // this lane's half of the running row sum
 #endif
+    bf16x8 kaug, maug[QB];      // FOLD: A operand (ones at k = 0, 1) and B operand (-m as hi + lo bf16)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kaug[e] = (hh == 0 && e < 2) ? (__bf16)1.0f : (__bf16)0.0f;
 #pragma unroll
     for (int i = 0; i < QB; ++i) {
-        m_run[i] = -INFINITY;
+        m_run[i] = FOLD ? 0.f : -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) maug[i][e] = (__bf16)0.0f;
 #if LTXMI_ATTN_ONES
         lT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #else
@@ -230,6 +248,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sT[i][kb][e] = 0.f;
+                if (FOLD) sT[i][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kaug, maug[i], sT[i][kb], 0, 0, 0);
 #pragma unroll
                 for (int ks = 0; ks < C::KSTEPS; ++ks) {
                     const bf16x8 kf = *(const bf16x8*)(s + k_rd[kb] + (((2 * ks + hh) ^ k_sw0) << 4));
@@ -271,26 +290,61 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
                 mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
-            const float m_new = fmaxf(m_run[i], mt);
-            // rescale only when some row's max moved (wave-uniform branch): after the first few
-            // tiles the running max is stable for most tiles and the O-wide multiply is skipped
-            if (__any(m_new != m_run[i])) {
-                asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
-                const float alpha = HAS_BIAS ? fast_exp2(m_run[i] - m_new) : fast_exp2((m_run[i] - m_new) * c);
+            float nmoff = 0.f;                                   // -(max in the exponent's domain)
+            if (FOLD) {
+                // sT already holds x - m_run.  The max moved iff some element is > 0 (always on the
+                // first tile, where m_run = 0 is only a placeholder).  m is kept on a 1/4 grid
+                // (rounded UP, so p <= 1) which makes -m exactly representable as hi + lo bf16.
+                const bool first = (t == 0);
+                if (first || __any(mt > 0.f)) {
+                    asm volatile("; max-moved branch (kept a real branch: not if-converted)" ::: "memory");
+                    const float dq = (first || mt > 0.f) ? ceilf(mt * 4.0f) * 0.25f : 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) sT[i][kb][e] -= dq;
+                    if (!first) {
+                        const float alpha = fast_exp2(-dq);
 #if LTXMI_ATTN_ONES
-                // lane n (< 16) holds the sums of queries n (reg 0) and n + 16 (reg 1)
-                lT[i][0] *= alpha;
-                lT[i][1] *= __shfl(alpha, (lane + 16) & 63, 64);
+                        lT[i][0] *= alpha;
+                        lT[i][1] *= __shfl(alpha, (lane + 16) & 63, 64);
 #else
-                l_run[i] *= alpha;
+                        l_run[i] *= alpha;
 #endif
 #pragma unroll
-                for (int d = 0; d < C::DBLK; ++d)
+                        for (int d = 0; d < C::DBLK; ++d)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) oT[i][d][e] *= alpha;
-                m_run[i] = m_new;
+                            for (int e = 0; e < 16; ++e) oT[i][d][e] *= alpha;
+                    }
+                    m_run[i] += dq;
+                    const float nm = -m_run[i];
+                    const __bf16 mh = (__bf16)nm;
+                    const __bf16 ml = (__bf16)(nm - (float)mh);
+                    maug[i][0] = hh == 0 ? mh : (__bf16)0.0f;
+                    maug[i][1] = hh == 0 ? ml : (__bf16)0.0f;
+                }
+            } else {
+                const float m_new = fmaxf(m_run[i], mt);
+                // rescale only when some row's max moved (wave-uniform branch): after the first few
+                // tiles the running max is stable for most tiles and the O-wide multiply is skipped
+                if (__any(m_new != m_run[i])) {
+                    asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
+                    const float alpha = fast_exp2(m_run[i] - m_new);
+#if LTXMI_ATTN_ONES
+                    // lane n (< 16) holds the sums of queries n (reg 0) and n + 16 (reg 1)
+                    lT[i][0] *= alpha;
+                    lT[i][1] *= __shfl(alpha, (lane + 16) & 63, 64);
+#else
+                    l_run[i] *= alpha;
+#endif
+#pragma unroll
+                    for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) oT[i][d][e] *= alpha;
+                    m_run[i] = m_new;
+                }
+                nmoff = -m_run[i];
             }
-            const float nmoff = HAS_BIAS ? -m_run[i] : -m_run[i] * c;   // -(max in the exponent's domain)
 
             // ---------------- P = exp2(x - m), bf16 fragments
             bf16x8 pf[4];
@@ -301,8 +355,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float x = HAS_BIAS ? (sT[i][kb][e] + nmoff) : __builtin_fmaf(sT[i][kb][e], c, nmoff);
-                    sT[i][kb][e] = fast_exp2(x);
+                    sT[i][kb][e] = fast_exp2(FOLD ? sT[i][kb][e] : sT[i][kb][e] + nmoff);
 #if !LTXMI_ATTN_ONES
                     lsum += sT[i][kb][e];
 #endif

@@ -315,6 +315,12 @@ class CausalVideoAutoencoder(nn.Module):
                           spatial_padding_mode=config.get("spatial_padding_mode", "zeros"))
         return CausalVideoAutoencoder(decoder, latent_channels=config["latent_channels"], dims=dims, config=config)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *args, device="cuda", dtype=BF16, **kwargs):
+        """causal_video_autoencoder.py:34-120 (decode side): diffusers directory or single file."""
+        from .loading import load_vae
+        return load_vae(pretrained_model_name_or_path, device=device, dtype=dtype)
+
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):   # :248-298
         if any(k.startswith("vae.") for k in state_dict.keys()):
             state_dict = {k.replace("vae.", ""): v for k, v in state_dict.items() if k.startswith("vae.")}

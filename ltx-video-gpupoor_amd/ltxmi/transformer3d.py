@@ -141,6 +141,12 @@ class Transformer3DModel(nn.Module):
     def from_config(cls, config):
         return cls(**{k: v for k, v in dict(config).items() if not k.startswith("_")})
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, *args, device="cuda", dtype=torch.bfloat16, **kwargs):
+        """transformer3d.py:271-326: diffusers directory or single-file safetensors with a config blob."""
+        from .loading import load_transformer
+        return load_transformer(pretrained_model_path, device=device, dtype=dtype)
+
     def load_state_dict(self, state_dict: Dict, *args, **kwargs):              # transformer3d.py:257-269
         if any(k.startswith("model.diffusion_model.") for k in state_dict.keys()):
             state_dict = {k.replace("model.diffusion_model.", ""): v for k, v in state_dict.items()
