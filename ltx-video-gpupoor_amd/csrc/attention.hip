@@ -67,6 +67,9 @@ struct AttnCfg {
     }
 };
 
+#ifndef LTXMI_ATTN_MAXTREE
+#define LTXMI_ATTN_MAXTREE 1
+#endif
 #ifndef LTXMI_ATTN_ONES
 #define LTXMI_ATTN_ONES 1      // 1: row sums on the matrix pipe (masked all-ones A operand) instead of v_add
 #endif
@@ -281,11 +284,30 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
                         if (key >= p.Lk) sT[i][kb][e] = -INFINITY;
                     }
             }
+#if LTXMI_ATTN_MAXTREE
+            // row max as a shallow tree (depth 4 with v_max3_f32) instead of one 32-deep dependent
+            // chain.  Built with -fno-honor-nans (attention.o only): without it hipcc puts a
+            // canonicalising v_max in front of every MFMA output that feeds fmaxf.
+            float mt;
+            {
+                auto max3 = [](float a, float b, float c3) { return fmaxf(fmaxf(a, b), c3); };
+                float l1[11];
+#pragma unroll
+                for (int g = 0; g < 5; ++g) {
+                    l1[g] = max3(sT[i][0][3 * g], sT[i][0][3 * g + 1], sT[i][0][3 * g + 2]);
+                    l1[5 + g] = max3(sT[i][1][3 * g], sT[i][1][3 * g + 1], sT[i][1][3 * g + 2]);
+                }
+                l1[10] = max3(sT[i][0][15], sT[i][1][15], l1[0]);
+                const float a = max3(l1[1], l1[2], l1[3]), b2 = max3(l1[4], l1[5], l1[6]), c2 = max3(l1[7], l1[8], l1[9]);
+                mt = fmaxf(max3(a, b2, c2), l1[10]);
+            }
+#else
             float mt = sT[i][0][0];
 #pragma unroll
             for (int e = 1; e < 16; ++e) mt = fmaxf(mt, sT[i][0][e]);
 #pragma unroll
             for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sT[i][1][e]);
+#endif
             {
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
                 mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
                 // tiles the running max is stable for most tiles and the O-wide multiply is skipped
                 if (__any(m_new != m_run[i])) {
                     asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
-                    const float alpha = fast_exp2(m_run[i] - m_new);
+                    const float alpha = HAS_BIAS ? fast_exp2(m_run[i] - m_new) : fast_exp2((m_run[i] - m_new) * c);
 #if LTXMI_ATTN_ONES
                     // lane n (< 16) holds the sums of queries n (reg 0) and n + 16 (reg 1)
                     lT[i][0] *= alpha;
@@ -343,7 +365,7 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
                         for (int e = 0; e < 16; ++e) oT[i][d][e] *= alpha;
                     m_run[i] = m_new;
                 }
-                nmoff = -m_run[i];
+                nmoff = HAS_BIAS ? -m_run[i] : -m_run[i] * c;
             }
 
             // ---------------- P = exp2(x - m), bf16 fragments
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    sT[i][kb][e] = fast_exp2(FOLD ? sT[i][kb][e] : sT[i][kb][e] + nmoff);
+                    sT[i][kb][e] = fast_exp2(FOLD ? sT[i][kb][e] : (HAS_BIAS ? sT[i][kb][e] + nmoff : __builtin_fmaf(sT[i][kb][e], c, nmoff)));
 #if !LTXMI_ATTN_ONES
                     lsum += sT[i][kb][e];
 #endif

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libltxmi.so")
+# LTXMI_LIB: tuning knob only (A/B runs of two builds of the SAME library); never a fallback path
+LIB_PATH = os.environ.get("LTXMI_LIB") or os.path.join(_HERE, "libltxmi.so")
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 
