@@ -256,7 +256,7 @@ def main():
                        "tokens": N_TOK, "b_eff": NUM_CONDS, "layers": L, "parallelism": f"replicas x{world}",
                        "algorithmic_tflop_per_step": 66.4},
             "step_tflops": round(66.4 / (ms_per_step * 1e-3), 1),
-            "roofline": {"kernel": "gemm_bf16_nt_kernel<256,256,2,4,GELU_TANH> (ff.net.0, M=14976 N=8192 K=2048)",
+            "roofline": {"kernel": "gemm_bf16_nt_persistent_kernel<256,256,2,4,GELU_TANH> (ff.net.0, M=14976 N=8192 K=2048)",
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                          "traffic": traffic, "launch_ms": round(ff1_ms, 4), "launches_timed": len(ff1),

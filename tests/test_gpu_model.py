@@ -289,3 +289,33 @@ def test_pipeline_config1_two_steps():
     e = rel(out, truth)
     print(f"pipeline 2 steps: rel L2 {e:.3e}")
     assert e < 1e-2
+
+
+def test_ulysses_processor_world1_matches_default_processor():
+    """The sequence-parallel code path (UlyssesAttnProcessor + usp_dit_forward) on the GPU with a
+    1-rank RCCL group: the all-to-alls are identities, so the result must equal the default
+    processor's bit for bit (same kernels, same order)."""
+    import os
+    import torch.distributed as dist
+    from ltxmi import distributed as sp
+    grid, B, T = (2, 4, 8), 3, 24
+    cfg, sd32, x, enc, mask, ts, frac = dit_case(2, 64, 2, grid, B, T, seed=11)
+    m = build_model(cfg, sd32)
+    fc = m.precompute_freqs_cis(frac.to(DEV))
+    kw = dict(encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV), timestep=ts.to(DEV),
+              latent_shape=grid, ltxv_model=_Holder())
+    ref = m(x.to(DEV), freqs_cis=fc, return_dict=False, **kw)[0]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        sp.enable_sequence_parallel(m)
+        out = sp.usp_dit_forward(m, x.to(DEV), fc, **kw)[0]
+        torch.cuda.synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert torch.equal(out, ref)
