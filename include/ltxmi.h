@@ -152,6 +152,7 @@ int ltxmi_stg_blend_bf16(void* a, int64_t lda, const void* v, int64_t ldv,
  *   time:  replicate (k-1) frames in front when causal, else (k-1)/2 on both sides
  *          ltx_video/models/autoencoders/causal_conv3d.py:44-59
  *   space: pad 1, zeros or replicate (nn.Conv3d padding_mode)   causal_conv3d.py:33-42
+ * With strides the output grid is nn.Conv3d's: floor((L + pad - 3) / stride) + 1 per axis.
  * x: [B, T, H, W, Cin]; w: [Cout, 27, Cin] (tap-major, K contiguous; repacked from the
  * checkpoint's [Cout,Cin,3,3,3] once at load); bias [Cout]; y: [B, T, H, W, Cout].
  * Optional fused output transform (DepthToSpaceUpsample, causal_video_autoencoder.py:1051-1065):
@@ -170,6 +171,12 @@ typedef struct ltxmi_conv3d_args {
     int32_t res_channels;      /* channels of the residual tensor (Cin of the block)      */
     const void* add;           /* plain store only: y = conv + add, add [B,T,H,W,Cout] or NULL
                                   (ResnetBlock3D skip, causal_video_autoencoder.py:1256)   */
+    /* encoder-side extensions (0 = default): strided causal convolutions of the "compress_*"
+     * encoder blocks (causal_video_autoencoder.py:395-432) and the extended-in-time convolution of
+     * SpaceToDepthDownsample, which runs on the input with its first frame duplicated (:991-1009):
+     * tpad = frames replicated in front (default 2 causal / 1 otherwise), out_T = output frames. */
+    int32_t stride_t, stride_hw;   /* 1 or 2                                                */
+    int32_t tpad, out_T;
 } ltxmi_conv3d_args;
 
 int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* args, void* stream);
@@ -199,6 +206,26 @@ int ltxmi_ncdhw_to_ndhwc_bf16(const void* z, void* y, int32_t B, int32_t C, int3
                               int32_t W, const float* std, const float* mean, void* stream);
 int ltxmi_unpatchify_to_ncdhw_bf16(const void* x, void* y, int32_t B, int32_t T, int32_t H, int32_t W,
                                    int32_t C_out, int32_t patch, void* stream);
+
+/* Encoder side (image / video conditioning; Encoder.forward, causal_video_autoencoder.py:514-557):
+ *  patchify:       pixels NCDHW [B,C,T,H,W] -> NDHWC [B,T,H/p,W/p,C_pad], channel (c p r q) =
+ *                  "b c (f p) (h q) (w r) -> b (c p r q) f h w" with p=1 (:1261-1279); channels
+ *                  >= C*p*p are zero so that conv_in's K axis is a multiple of 64
+ *  space_to_depth_skip: tail of SpaceToDepthDownsample.forward (:991-1020).  conv = the stride-1
+ *                  causal convolution of the block ([B,T',H,W,Cconv], T' = T+1 when stride_t == 2,
+ *                  i.e. run with tpad = 3 / out_T = T+1 on x), x = the block input [B,T,H,W,Cin];
+ *                  out [B,T'/st,H/s,W/s,Cconv*st*s*s] = space_to_depth(conv) + group-mean of
+ *                  space_to_depth(x with its first frame duplicated), group = Cin / Cconv
+ *  ndhwc_to_ncdhw: channels c0..c0+C of NDHWC rows (row stride ldx) -> NCDHW [B,C,T,H,W], optionally
+ *                  (v - mean[c]) / std[c] (normalize_latents, vae_encode.py:228-236) */
+int ltxmi_patchify_to_ndhwc_bf16(const void* x, void* y, int32_t B, int32_t C, int32_t T, int32_t H,
+                                 int32_t W, int32_t patch, int32_t C_pad, void* stream);
+int ltxmi_space_to_depth_skip_bf16(const void* conv, const void* x, void* out, int32_t B, int32_t T,
+                                   int32_t H, int32_t W, int32_t Cin, int32_t Cconv, int32_t stride_t,
+                                   int32_t stride_hw, int32_t group, void* stream);
+int ltxmi_ndhwc_to_ncdhw_bf16(const void* x, int64_t ldx, int32_t c0, void* y, int32_t B, int32_t C,
+                              int32_t T, int32_t H, int32_t W, const float* std, const float* mean,
+                              void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Denoise-loop step math kept on device (no host sync per step).

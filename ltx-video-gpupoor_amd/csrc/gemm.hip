@@ -44,7 +44,9 @@ struct GemmParams {
     int rows_per_group;
     int tiles_m, tiles_n;
     // implicit-GEMM convolution (MODE == 1): A rows are gathered from x [B,T,H,W,Cin]
-    int cB, cT, cH, cW, cCin;
+    int cB, cT, cH, cW, cCin;      // input grid
+    int oT, oH, oW;                 // output grid (== input grid unless strided / extended in time)
+    int sT, sHW;                    // strides (1 or 2)
     int tpad;            // frames replicated in front (2 causal, 1 otherwise)
     int pad_replicate;   // spatial padding mode
     // depth-to-space epilogue (EPI == EPI_D2S)
@@ -108,12 +110,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
         if (MODE == 0) {
             a_src[j] = p.A + (int64_t)g * p.lda + ((sslot ^ (row & 7)) << 3);
         } else {
-            cv_x[j] = g % p.cW;
-            const int r1 = g / p.cW;
-            cv_y[j] = r1 % p.cH;
-            const int r2 = r1 / p.cH;
-            cv_t[j] = r2 % p.cT;
-            const int bb = r2 / p.cT;
+            cv_x[j] = (g % p.oW) * p.sHW;
+            const int r1 = g / p.oW;
+            cv_y[j] = (r1 % p.oH) * p.sHW;
+            const int r2 = r1 / p.oH;
+            cv_t[j] = (r2 % p.oT) * p.sT;
+            const int bb = r2 / p.oT;
             a_src[j] = p.A + (int64_t)bb * p.cT * p.cH * p.cW * p.cCin + ((sslot ^ (row & 7)) << 3);
         }
     }
@@ -751,7 +753,7 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     p.gate_ld = a->gate_ld;
     p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
     p.tiles_m = p.tiles_n = 0;
-    p.cB = p.cT = p.cH = p.cW = p.cCin = 1; p.tpad = 0; p.pad_replicate = 0; p.res = nullptr; p.res_ch = 0;
+    p.cB = p.cT = p.cH = p.cW = p.cCin = 1; p.oT = p.oH = p.oW = 1; p.sT = p.sHW = 1; p.tpad = 0; p.pad_replicate = 0; p.res = nullptr; p.res_ch = 0;
     hipStream_t s = (hipStream_t)stream;
     const int epi = (a->epilogue == LTXMI_EPI_GATE_RESIDUAL && !a->gate_table) ? EPI_RESIDUAL : a->epilogue;
     // Tile choice: 256x256 (8 waves) when it still fills the 256 CUs, else 128x128 (4 waves,
@@ -775,7 +777,18 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
                   "ltxmi_conv3d_ndhwc_bf16: non-positive shape");
     LTXMI_REQUIRE(a->Cin % 64 == 0, LTXMI_ERR_UNSUPPORTED, "ltxmi_conv3d_ndhwc_bf16: Cin=%d must be a multiple of 64", a->Cin);
     LTXMI_REQUIRE(a->Cout % 8 == 0, LTXMI_ERR_UNSUPPORTED, "ltxmi_conv3d_ndhwc_bf16: Cout=%d must be a multiple of 8", a->Cout);
-    const int64_t M = (int64_t)a->B * a->T * a->H * a->W;
+    const int sT = a->stride_t > 0 ? a->stride_t : 1, sHW = a->stride_hw > 0 ? a->stride_hw : 1;
+    LTXMI_REQUIRE((sT == 1 || sT == 2) && (sHW == 1 || sHW == 2), LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_conv3d_ndhwc_bf16: strides must be 1 or 2");
+    // output grid: nn.Conv3d arithmetic on the padded input (time padded by tpad frames in front, and by
+    // one replicated frame behind when not causal; space padded by 1): floor((L + pad - 3) / s) + 1
+    const int tpad_front = a->tpad > 0 ? a->tpad : (a->causal ? 2 : 1);
+    const int tpad_back = (a->tpad > 0 || a->causal) ? 0 : 1;
+    const int oT = a->out_T > 0 ? a->out_T : (a->T + tpad_front + tpad_back - 3) / sT + 1;
+    const int oH = (a->H + 2 - 3) / sHW + 1, oW = (a->W + 2 - 3) / sHW + 1;
+    LTXMI_REQUIRE(!(a->d2s && (sT != 1 || sHW != 1 || oT != a->T)), LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_conv3d_ndhwc_bf16: depth-to-space store needs a stride-1, same-size convolution");
+    const int64_t M = (int64_t)a->B * oT * oH * oW;
     LTXMI_REQUIRE(M < (1ll << 31) && (int64_t)a->B * (2 * a->T) * (2 * a->H) * (2 * a->W) < (1ll << 31),
                   LTXMI_ERR_UNSUPPORTED, "ltxmi_conv3d_ndhwc_bf16: too many positions");
     if (a->d2s) {
@@ -798,7 +811,8 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
     p.R = nullptr; p.ldr = 0; p.gate_table = nullptr; p.gate_temb = nullptr; p.gate_ld = 0; p.rows_per_group = 1;
     p.tiles_m = p.tiles_n = 0;
     p.cB = a->B; p.cT = a->T; p.cH = a->H; p.cW = a->W; p.cCin = a->Cin;
-    p.tpad = a->causal ? 2 : 1;
+    p.oT = oT; p.oH = oH; p.oW = oW; p.sT = sT; p.sHW = sHW;
+    p.tpad = a->tpad > 0 ? a->tpad : (a->causal ? 2 : 1);
     p.pad_replicate = a->pad_replicate;
     p.res = a->d2s ? (const uint16_t*)a->residual : nullptr;
     p.res_ch = a->res_channels;

@@ -100,6 +100,73 @@ __global__ void unpatchify_kernel(const uint16_t* __restrict__ x, uint16_t* __re
     }
 }
 
+// x [B,C,T,H,W] pixels -> y [B,T,H/P,W/P,Cpad], channel n = (c*P + r)*P + q holds pixel (h*P+q, w*P+r);
+// channels >= C*P*P are zero (pads K of the first convolution to a multiple of 64)
+__global__ void patchify_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int C, int T, int H, int W,
+                                int P, int Cpad, int64_t total) {
+    const int Hp = H / P, Wp = W / P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % Cpad);
+        int64_t r0 = i / Cpad;
+        const int w = (int)(r0 % Wp); r0 /= Wp;
+        const int h = (int)(r0 % Hp); r0 /= Hp;
+        const int t = (int)(r0 % T);
+        const int64_t b = r0 / T;
+        uint16_t v = 0;
+        if (n < C * P * P) {
+            const int c = n / (P * P), r = (n / P) % P, q = n % P;
+            v = x[(((b * C + c) * T + t) * H + h * P + q) * (int64_t)W + w * P + r];
+        }
+        y[i] = v;
+    }
+}
+
+// SpaceToDepthDownsample tail: out[b,d,h,w, c*P + p] = conv[b, d*st+p1, h*s+p2, w*s+p3, c]
+//   + mean_j xdup[.. channel k = co*g + j -> (ci = k / P, p' = k % P)], xdup = x with its first frame
+// duplicated when st == 2 (conv then has T+1 frames).
+__global__ void space_to_depth_skip_kernel(const uint16_t* __restrict__ conv, const uint16_t* __restrict__ x,
+                                           uint16_t* __restrict__ out, int T, int H, int W, int Cin, int Cc,
+                                           int st, int s, int group, int64_t total) {
+    const int P = st * s * s, Co = Cc * P;
+    const int Tc = st == 2 ? T + 1 : T;
+    const int Do = Tc / st, Ho = H / s, Wo = W / s;
+    const float inv_g = 1.0f / (float)group;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Co);
+        int64_t r0 = i / Co;
+        const int w = (int)(r0 % Wo); r0 /= Wo;
+        const int h = (int)(r0 % Ho); r0 /= Ho;
+        const int d = (int)(r0 % Do);
+        const int64_t b = r0 / Do;
+        const int c = co / P, p = co % P;
+        const int p1 = p / (s * s), p2 = (p / s) % s, p3 = p % s;
+        float v = bf2f(conv[(((b * Tc + d * st + p1) * H + h * s + p2) * (int64_t)W + w * s + p3) * Cc + c]);
+        float acc = 0.f;
+        for (int j = 0; j < group; ++j) {
+            const int k = co * group + j;
+            const int ci = k / P, pp = k % P;
+            int tt = d * st + pp / (s * s);
+            if (st == 2) tt = tt > 0 ? tt - 1 : 0;
+            acc += bf2f(x[(((b * T + tt) * H + h * s + (pp / s) % s) * (int64_t)W + w * s + pp % s) * Cin + ci]);
+        }
+        out[i] = f2bf(v + acc * inv_g);
+    }
+}
+
+// x rows [B*thw, ldx], channels c0..c0+C  ->  y [B,C,T,H,W], optionally (v - mean[c]) / std[c]
+__global__ void ndhwc_to_ncdhw_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int64_t ldx, int c0,
+                                      int C, int64_t thw, int64_t total, const float* __restrict__ std,
+                                      const float* __restrict__ mean) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pos = i % thw;
+        const int c = (int)((i / thw) % C);
+        const int64_t b = i / (thw * C);
+        float v = bf2f(x[(b * thw + pos) * ldx + c0 + c]);
+        if (std) v = (v - mean[c]) / std[c];
+        y[i] = f2bf(v);
+    }
+}
+
 // ---------------------------------------------------------------- guidance + Euler step
 // ws[0]=sum(text*uncond) ws[1]=sum(uncond^2) ws[2]=sum(text) ws[3]=sum(text^2) ws[4]=sum(out) ws[5]=sum(out^2)
 struct GuidanceP {
@@ -282,4 +349,53 @@ extern "C" int ltxmi_guidance_step_bf16(const void* noise_pred, int64_t n, int32
     hipLaunchKernelGGL(guidance_reduce2, dim3(g), dim3(PW_THREADS), 0, s, p);
     hipLaunchKernelGGL(guidance_apply, dim3(g), dim3(PW_THREADS), 0, s, p);
     return check_launch("ltxmi_guidance_step_bf16");
+}
+
+extern "C" int ltxmi_patchify_to_ndhwc_bf16(const void* x, void* y, int32_t B, int32_t C, int32_t T, int32_t H,
+                                            int32_t W, int32_t patch, int32_t C_pad, void* stream) {
+    LTXMI_REQUIRE(x && y, LTXMI_ERR_INVALID_ARG, "ltxmi_patchify_to_ndhwc_bf16: NULL argument");
+    LTXMI_REQUIRE(B > 0 && C > 0 && T > 0 && H > 0 && W > 0 && patch > 0, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_patchify_to_ndhwc_bf16: non-positive size");
+    LTXMI_REQUIRE(H % patch == 0 && W % patch == 0 && C_pad >= C * patch * patch, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_patchify_to_ndhwc_bf16: H=%d W=%d must be multiples of patch=%d and C_pad=%d >= C*patch^2",
+                  H, W, patch, C_pad);
+    const int64_t total = (int64_t)B * T * (H / patch) * (W / patch) * C_pad;
+    hipLaunchKernelGGL(patchify_kernel, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, C, T, H, W, patch, C_pad, total);
+    return check_launch("ltxmi_patchify_to_ndhwc_bf16");
+}
+
+extern "C" int ltxmi_space_to_depth_skip_bf16(const void* conv, const void* x, void* out, int32_t B, int32_t T,
+                                              int32_t H, int32_t W, int32_t Cin, int32_t Cconv, int32_t stride_t,
+                                              int32_t stride_hw, int32_t group, void* stream) {
+    LTXMI_REQUIRE(conv && x && out, LTXMI_ERR_INVALID_ARG, "ltxmi_space_to_depth_skip_bf16: NULL argument");
+    LTXMI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && Cin > 0 && Cconv > 0 && group > 0, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_space_to_depth_skip_bf16: non-positive size");
+    LTXMI_REQUIRE((stride_t == 1 || stride_t == 2) && (stride_hw == 1 || stride_hw == 2), LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_space_to_depth_skip_bf16: strides must be 1 or 2");
+    const int P = stride_t * stride_hw * stride_hw;
+    const int Tc = stride_t == 2 ? T + 1 : T;
+    LTXMI_REQUIRE(Tc % stride_t == 0 && H % stride_hw == 0 && W % stride_hw == 0, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_space_to_depth_skip_bf16: frames(+1)=%d H=%d W=%d not divisible by the strides", Tc, H, W);
+    LTXMI_REQUIRE((int64_t)Cconv * P * group == (int64_t)Cin * P, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_space_to_depth_skip_bf16: Cconv*group=%d must equal Cin=%d", Cconv * group, Cin);
+    const int64_t total = (int64_t)B * (Tc / stride_t) * (H / stride_hw) * (W / stride_hw) * Cconv * P;
+    hipLaunchKernelGGL(space_to_depth_skip_kernel, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)conv, (const uint16_t*)x, (uint16_t*)out, T, H, W, Cin, Cconv, stride_t,
+                       stride_hw, group, total);
+    return check_launch("ltxmi_space_to_depth_skip_bf16");
+}
+
+extern "C" int ltxmi_ndhwc_to_ncdhw_bf16(const void* x, int64_t ldx, int32_t c0, void* y, int32_t B, int32_t C,
+                                         int32_t T, int32_t H, int32_t W, const float* std, const float* mean,
+                                         void* stream) {
+    LTXMI_REQUIRE(x && y, LTXMI_ERR_INVALID_ARG, "ltxmi_ndhwc_to_ncdhw_bf16: NULL argument");
+    LTXMI_REQUIRE(B > 0 && C > 0 && T > 0 && H > 0 && W > 0 && c0 >= 0 && ldx >= c0 + C, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_ndhwc_to_ncdhw_bf16: bad sizes");
+    LTXMI_REQUIRE((std == nullptr) == (mean == nullptr), LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_ndhwc_to_ncdhw_bf16: std and mean come together");
+    const int64_t thw = (int64_t)T * H * W, total = (int64_t)B * C * thw;
+    hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, ldx, c0, C, thw, total, std, mean);
+    return check_launch("ltxmi_ndhwc_to_ncdhw_bf16");
 }

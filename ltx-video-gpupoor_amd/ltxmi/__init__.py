@@ -8,7 +8,8 @@ from . import _lib  # noqa: F401  (fails loudly when libltxmi.so is absent)
 from .attention import (Attention, AttnProcessor2_0, BasicTransformerBlock, FeedForward,  # noqa: F401
                         SkipLayerStrategy)
 from .attention_seam import pay_attention  # noqa: F401
-from .autoencoder import CausalVideoAutoencoder, DecoderOutput, vae_decode  # noqa: F401
+from .autoencoder import (CausalVideoAutoencoder, DecoderOutput, AutoencoderKLOutput,  # noqa: F401
+                          DiagonalGaussianDistribution, vae_decode, vae_encode)
 from .patchifier import SymmetricPatchifier, latent_to_pixel_coords_from_factors  # noqa: F401
 from .pipeline import LTXVideoPipeline  # noqa: F401
 from .scheduler import RectifiedFlowScheduler  # noqa: F401

@@ -34,7 +34,8 @@ class Conv3dArgs(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("y", c_void_p),
                 ("B", c_int), ("T", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
                 ("causal", c_int), ("pad_replicate", c_int), ("d2s", c_int), ("residual", c_void_p),
-                ("res_channels", c_int), ("add", c_void_p)]
+                ("res_channels", c_int), ("add", c_void_p),
+                ("stride_t", c_int), ("stride_hw", c_int), ("tpad", c_int), ("out_T", c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/ltxmi.h one to one
@@ -61,6 +62,12 @@ SIGNATURES = {
                                           c_void_p, c_void_p]),
     "ltxmi_unpatchify_to_ncdhw_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                c_void_p]),
+    "ltxmi_patchify_to_ndhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             c_void_p]),
+    "ltxmi_space_to_depth_skip_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                               c_int, c_int, c_int, c_int, c_void_p]),
+    "ltxmi_ndhwc_to_ncdhw_bf16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p]),
     "ltxmi_guidance_step_bf16": (c_int, [c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_int, c_int,
                                          c_void_p, c_int, c_float, c_void_p, c_void_p]),
 }

@@ -1,4 +1,4 @@
-"""``CausalVideoAutoencoder`` (decode side) on libltxmi kernels.
+"""``CausalVideoAutoencoder`` (decode and encode) on libltxmi kernels.
 
 Drop-in for the reference's decode path:
   CausalVideoAutoencoder / from_config     ltx_video/models/autoencoders/causal_video_autoencoder.py:33-177
@@ -14,7 +14,12 @@ implicit GEMM whose K axis (tap, cin) is contiguous in HBM; the reference's temp
 replicate-pad ``torch.concatenate`` (causal_conv3d.py:46-57) and spatial padding are folded into
 the kernel's address computation, PixelNorm + AdaLN + SiLU are one pass, and the
 depth-to-space rearranges + residual of DepthToSpaceUpsample are the conv's store pattern.
-The encoder is not part of this round's path.
+The encode side (image/video conditioning) reuses the same kernels:
+  Encoder / SpaceToDepthDownsample        causal_video_autoencoder.py:317-557, 976-1020
+  AutoencoderKLWrapper.encode (+tiling)   vae.py:156-191, 265-341
+  vae_encode / normalize_latents          vae_encode.py:22-91, 228-236
+strided CausalConv3d is the implicit GEMM with a strided row->position map, patchify writes the
+NDHWC layout directly, and SpaceToDepthDownsample's duplicated first frame is a padding parameter.
 """
 import math
 from dataclasses import dataclass
@@ -34,6 +39,43 @@ class DecoderOutput:
     sample: torch.Tensor
 
 
+class DiagonalGaussianDistribution:
+    """The diffusers leaf the reference wraps the encoder moments in (vae.py:308): mean / logvar
+    (clamped to [-30, 20]) with ``sample()`` = mean + std * randn and ``mode()`` = mean.  Built from
+    the two halves directly (the reference's ``parameters`` tensor is their concatenation)."""
+
+    def __init__(self, mean, logvar):
+        self.mean = mean
+        if logvar is None:                                   # latent_log_var == "none"
+            self.logvar = torch.full_like(mean, -30.0)
+            self.deterministic = True
+        else:
+            self.logvar = torch.clamp(logvar.float(), -30.0, 20.0)
+            self.deterministic = False
+
+    @property
+    def parameters(self):
+        return torch.cat([self.mean, self.logvar.to(self.mean.dtype)], dim=1)
+
+    @property
+    def std(self):
+        return torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator: Optional[torch.Generator] = None):
+        if self.deterministic:
+            return self.mean
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=torch.float32)
+        return (self.mean.float() + self.std * noise).to(self.mean.dtype)
+
+    def mode(self):
+        return self.mean
+
+
+@dataclass
+class AutoencoderKLOutput:
+    latent_dist: DiagonalGaussianDistribution
+
+
 class _Conv3dParams(nn.Module):
     """Holds ``weight [Cout,Cin,k,k,k]`` / ``bias`` under the name ``conv`` like nn.Conv3d."""
 
@@ -45,17 +87,24 @@ class _Conv3dParams(nn.Module):
 
 
 class CausalConv3d(nn.Module):
-    """causal_conv3d.py:7-63.  Kernel 3, stride 1; time padding by frame replication
-    (2 in front when causal, 1+1 otherwise), spatial padding 1 in ``spatial_padding_mode``."""
+    """causal_conv3d.py:7-63.  Kernel 3, stride 1 or 2 per axis; time padding by frame replication
+    (2 in front when causal, 1+1 otherwise), spatial padding 1 in ``spatial_padding_mode``.
+    The packed weight pads Cin up to a multiple of 64 and Cout up to a multiple of 8 with zeros
+    (conv_in of the encoder has 48 input channels, its conv_out 129 outputs); the result then has
+    ``cout_padded`` channels and the caller reads the first ``out_channels``."""
 
     def __init__(self, in_channels, out_channels, kernel_size: int = 3, stride=1, dilation=1, groups=1,
                  spatial_padding_mode: str = "zeros", **kwargs):
         super().__init__()
-        if kernel_size != 3 or stride != 1 or dilation != 1 or groups != 1:
-            raise NotImplementedError("ltxmi.CausalConv3d: only 3x3x3 / stride 1 / dense is on this path")
+        stride = (stride,) * 3 if isinstance(stride, int) else tuple(stride)
+        if kernel_size != 3 or dilation != 1 or groups != 1 or any(s not in (1, 2) for s in stride) \
+                or stride[1] != stride[2]:
+            raise NotImplementedError("ltxmi.CausalConv3d: only dense 3x3x3 with strides 1/2 is on this path")
         if spatial_padding_mode not in ("zeros", "replicate"):
             raise NotImplementedError(f"spatial_padding_mode {spatial_padding_mode}")
         self.in_channels, self.out_channels = in_channels, out_channels
+        self.cin_padded, self.cout_padded = -(-in_channels // 64) * 64, -(-out_channels // 8) * 8
+        self.stride = stride
         self.time_kernel_size = 3
         self.pad_replicate = spatial_padding_mode == "replicate"
         self.conv = _Conv3dParams(in_channels, out_channels, 3)
@@ -70,8 +119,13 @@ class CausalConv3d(nn.Module):
         key = (self.conv.weight.data_ptr(), d2s)
         if self._packed is None or self._packed[0] != key:
             with torch.no_grad():
-                w = self.conv.weight.permute(0, 2, 3, 4, 1).reshape(self.out_channels, -1)
+                w = self.conv.weight.permute(0, 2, 3, 4, 1)                  # [Cout, 3,3,3, Cin]
                 b = self.conv.bias
+                if self.cin_padded != self.in_channels or self.cout_padded != self.out_channels:
+                    w = torch.nn.functional.pad(w, (0, self.cin_padded - self.in_channels, 0, 0, 0, 0, 0, 0,
+                                                    0, self.cout_padded - self.out_channels))
+                    b = torch.nn.functional.pad(b, (0, self.cout_padded - self.out_channels))
+                w = w.reshape(self.cout_padded, -1)
                 if d2s:
                     cp = self.out_channels // 8
                     w = w.view(cp, 8, -1).transpose(0, 1).reshape(self.out_channels, -1)
@@ -87,15 +141,16 @@ class CausalConv3d(nn.Module):
         self._packed = None
         return super()._load_from_state_dict(*a, **k)
 
-    def forward(self, x, causal: bool = True, d2s=False, residual=None, add=None):
+    def forward(self, x, causal: bool = True, d2s=False, residual=None, add=None, tpad=0, out_T=0):
         """x: NDHWC bf16."""
         w, b = self.packed(d2s)
-        return ops.conv3d(x, w, b, causal, self.pad_replicate, d2s=d2s, residual=residual, add=add)
+        return ops.conv3d(x, w, b, causal, self.pad_replicate, d2s=d2s, residual=residual, add=add,
+                          stride=self.stride, tpad=tpad, out_T=out_T)
 
 
 def make_conv_nd(dims, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, causal=False, spatial_padding_mode="zeros", temporal_padding_mode="zeros"):
-    """conv_nd_factory.py:9-72, the (dims=3, causal=True) branch -- the only one the decoder uses."""
+    """conv_nd_factory.py:9-72, the (dims=3, causal=True) branch -- the only one the VAE uses."""
     if dims != 3 or not causal:
         raise NotImplementedError("ltxmi.make_conv_nd: only dims=3, causal=True is on this path")
     return CausalConv3d(in_channels, out_channels, kernel_size, stride=stride, dilation=dilation, groups=groups,
@@ -201,6 +256,108 @@ class DepthToSpaceUpsample(nn.Module):
         return self.conv(x, causal=causal, d2s=True, residual=x if self.residual else None)
 
 
+class SpaceToDepthDownsample(nn.Module):
+    """causal_video_autoencoder.py:976-1020.  The block's stride-1 convolution runs over the input
+    with its first frame duplicated (stride_t == 2): here that is the same convolution with three
+    replicated frames in front and T+1 output frames -- no concatenated copy -- and the two
+    rearranges + group-mean skip + add are one pass over the result."""
+
+    def __init__(self, dims, in_channels, out_channels, stride, spatial_padding_mode="zeros"):
+        super().__init__()
+        self.stride = tuple(stride)
+        prod = self.stride[0] * self.stride[1] * self.stride[2]
+        self.group_size = in_channels * prod // out_channels
+        self.conv = CausalConv3d(in_channels, out_channels // prod, 3, spatial_padding_mode=spatial_padding_mode)
+
+    def forward(self, x, causal: bool = True):
+        T = x.shape[1]
+        if self.stride[0] == 2:
+            y = self.conv(x, causal=causal, tpad=3 if causal else 2, out_T=T + 1)
+        else:
+            y = self.conv(x, causal=causal)
+        return ops.space_to_depth_skip(y, x, self.stride)
+
+
+class Encoder(nn.Module):
+    """causal_video_autoencoder.py:317-557 (dims=3, pixel_norm)."""
+
+    _STRIDES = {"compress_time": (2, 1, 1), "compress_space": (1, 2, 2), "compress_all": (2, 2, 2),
+                "compress_all_x_y": (2, 2, 2), "compress_all_res": (2, 2, 2), "compress_space_res": (1, 2, 2),
+                "compress_time_res": (2, 1, 1)}
+
+    def __init__(self, dims=3, in_channels=3, out_channels=3, blocks=(("res_x", 1),), base_channels=128,
+                 norm_num_groups=32, patch_size=1, norm_layer="group_norm", latent_log_var="per_channel",
+                 spatial_padding_mode="zeros"):
+        super().__init__()
+        if dims != 3 or norm_layer != "pixel_norm":
+            raise NotImplementedError("ltxmi.Encoder: dims=3 with pixel_norm only")
+        self.patch_size = patch_size
+        self.norm_layer = norm_layer
+        self.latent_channels = out_channels
+        self.latent_log_var = latent_log_var
+        self.blocks_desc = blocks
+        ch = base_channels
+        self.conv_in = make_conv_nd(dims, in_channels * patch_size ** 2, ch, 3, 1, 1, causal=True,
+                                    spatial_padding_mode=spatial_padding_mode)
+        self.down_blocks = nn.ModuleList([])
+        for name, params in blocks:
+            cin = ch
+            if isinstance(params, int):
+                params = {"num_layers": params}
+            if name == "res_x":
+                blk = UNetMidBlock3D(dims, cin, num_layers=params["num_layers"], resnet_eps=1e-6,
+                                     norm_layer=norm_layer, spatial_padding_mode=spatial_padding_mode)
+            elif name == "res_x_y":
+                ch = params.get("multiplier", 2) * ch
+                blk = ResnetBlock3D(dims, cin, ch, eps=1e-6, norm_layer=norm_layer,
+                                    spatial_padding_mode=spatial_padding_mode)
+            elif name in ("compress_time", "compress_space", "compress_all", "compress_all_x_y"):
+                if name == "compress_all_x_y":
+                    ch = params.get("multiplier", 2) * ch
+                blk = make_conv_nd(dims, cin, ch, 3, stride=self._STRIDES[name], causal=True,
+                                   spatial_padding_mode=spatial_padding_mode)
+            elif name in ("compress_all_res", "compress_space_res", "compress_time_res"):
+                ch = params.get("multiplier", 2) * ch
+                blk = SpaceToDepthDownsample(dims, cin, ch, self._STRIDES[name], spatial_padding_mode)
+            else:
+                raise ValueError(f"unknown block: {name}")
+            self.down_blocks.append(blk)
+        conv_out_channels = out_channels
+        if latent_log_var == "per_channel":
+            conv_out_channels *= 2
+        elif latent_log_var in ("uniform", "constant"):
+            conv_out_channels += 1
+        elif latent_log_var != "none":
+            raise ValueError(f"Invalid latent_log_var: {latent_log_var}")
+        self.conv_out = make_conv_nd(dims, ch, conv_out_channels, 3, padding=1, causal=True,
+                                     spatial_padding_mode=spatial_padding_mode)
+
+    def forward(self, sample):
+        """sample: pixels NCDHW bf16.  Returns conv_out's result NDHWC [B,f,h,w,cout_padded]; the
+        latent_log_var expansion of :531-555 is a view decision left to ``moments_ncdhw``."""
+        x = ops.patchify_to_ndhwc(sample, self.patch_size, self.conv_in.cin_padded)
+        x = self.conv_in(x, causal=True)
+        for blk in self.down_blocks:
+            x = blk(x, causal=True)
+        x = ops.pixelnorm_ada_silu(x, None, None, apply_silu=True, out=x)
+        return self.conv_out(x, causal=True)
+
+    def moments_ncdhw(self, y, std=None, mean=None):
+        """(mean, logvar) NCDHW from conv_out's NDHWC result, per ``latent_log_var`` (:531-555);
+        ``std``/``mean`` (fp32 [C]) fold normalize_latents (vae_encode.py:228-236) into the mean's layout pass."""
+        C = self.latent_channels
+        mu = ops.ndhwc_to_ncdhw(y, 0, C, std, mean)
+        if self.latent_log_var == "per_channel":
+            logvar = ops.ndhwc_to_ncdhw(y, C, C)
+        elif self.latent_log_var == "uniform":
+            logvar = ops.ndhwc_to_ncdhw(y, C, 1).expand(-1, C, -1, -1, -1)
+        elif self.latent_log_var == "constant":
+            logvar = torch.full_like(mu, -30.0)
+        else:
+            logvar = None
+        return mu, logvar
+
+
 class Decoder(nn.Module):
     """causal_video_autoencoder.py:560-802."""
 
@@ -284,8 +441,10 @@ class _Stats(nn.Module):
 
 
 class CausalVideoAutoencoder(nn.Module):
-    def __init__(self, decoder: Decoder, latent_channels=128, dims=3, config=None):
+    def __init__(self, decoder: Decoder, latent_channels=128, dims=3, config=None, encoder: Optional[Encoder] = None):
         super().__init__()
+        if encoder is not None:
+            self.encoder = encoder
         self.decoder = decoder
         self.dims = dims
         self._config = dict(config or {})
@@ -313,7 +472,18 @@ class CausalVideoAutoencoder(nn.Module):
                           timestep_conditioning=config.get("timestep_conditioning", False),
                           base_channels=config.get("decoder_base_channels", 128),
                           spatial_padding_mode=config.get("spatial_padding_mode", "zeros"))
-        return CausalVideoAutoencoder(decoder, latent_channels=config["latent_channels"], dims=dims, config=config)
+        encoder = None
+        if config.get("encoder_blocks", config.get("blocks")) is not None and config.get("build_encoder", True):
+            double_z = config.get("double_z", True)
+            encoder = Encoder(dims=dims, in_channels=config.get("in_channels", 3), out_channels=config["latent_channels"],
+                              blocks=config.get("encoder_blocks", config.get("blocks")),
+                              patch_size=config.get("patch_size", 1),
+                              latent_log_var=config.get("latent_log_var", "per_channel" if double_z else "none"),
+                              norm_layer=config.get("norm_layer", "group_norm"),
+                              base_channels=config.get("encoder_base_channels", 128),
+                              spatial_padding_mode=config.get("spatial_padding_mode", "zeros"))
+        return CausalVideoAutoencoder(decoder, latent_channels=config["latent_channels"], dims=dims, config=config,
+                                      encoder=encoder)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *args, device="cuda", dtype=BF16, **kwargs):
@@ -329,8 +499,8 @@ class CausalVideoAutoencoder(nn.Module):
         for k, v in state_dict.items():
             for a, b in remap.items():
                 k = k.replace(a, b)
-            if k.startswith("encoder."):
-                continue                                   # decode-only path
+            if k.startswith("encoder.") and not hasattr(self, "encoder"):
+                continue                                   # decode-only instance
             out[k] = v
         return super().load_state_dict(out, strict=strict, assign=assign)
 
@@ -390,6 +560,82 @@ class CausalVideoAutoencoder(nn.Module):
 
     def disable_hw_tiling(self):
         self.use_hw_tiling = False
+
+    # ---- encode ------------------------------------------------------------------------
+    def _encode(self, x, stats=None):                                            # vae.py:337-341
+        """pixels NCDHW -> (mean, logvar) NCDHW; ``stats`` folds normalize_latents into the mean."""
+        if not hasattr(self, "encoder"):
+            raise RuntimeError("ltxmi.CausalVideoAutoencoder: this instance was built without an encoder")
+        std, mean = stats if stats is not None else (None, None)
+        return self.encoder.moments_ncdhw(self.encoder(x.to(BF16)), std, mean)
+
+    @staticmethod
+    def _cat_moments(mv):
+        mu, lv = mv
+        return mu if lv is None else torch.cat([mu, lv], dim=1)
+
+    def _hw_tiled_encode(self, x):                                               # vae.py:156-191
+        overlap_size = int(self.tile_sample_min_size * (1 - self.tile_overlap_factor))
+        blend_extent = int(self.tile_latent_min_size * self.tile_overlap_factor)
+        row_limit = self.tile_latent_min_size - blend_extent
+        rows = []
+        for i in range(0, x.shape[3], overlap_size):
+            row = []
+            for j in range(0, x.shape[4], overlap_size):
+                tile = x[:, :, :, i:i + self.tile_sample_min_size, j:j + self.tile_sample_min_size]
+                row.append(self._cat_moments(self._encode(tile)))
+            rows.append(row)
+        result_rows = []
+        for i, row in enumerate(rows):
+            result_row = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self._blend(rows[i - 1][j], tile, blend_extent, 3)
+                if j > 0:
+                    tile = self._blend(row[j - 1], tile, blend_extent, 4)
+                result_row.append(tile[:, :, :, :row_limit, :row_limit])
+            result_rows.append(torch.cat(result_row, dim=4))
+        return torch.cat(result_rows, dim=3)
+
+    def encode(self, z, return_dict: bool = True, _stats=None):
+        """vae.py:265-312: pixels [B,3,F,H,W] -> AutoencoderKLOutput(latent_dist).  ``_stats`` (std, mean)
+        is vae_encode's per-channel normalisation, applied to the mean in the untiled case."""
+        if self.use_z_tiling and z.shape[2] > (self.z_sample_size + 1) > 1:
+            tl = self.z_sample_size
+            ts = tl * 8
+            overlap_size = int(ts * 0.75)
+            blend_extent = int(tl * 0.25)
+            t_limit = tl - blend_extent
+            row = []
+            for i in range(0, z.shape[2], overlap_size):
+                tile = z[:, :, i:i + ts + 1]
+                tile = self._hw_tiled_encode(tile) if self.use_hw_tiling else self._cat_moments(self._encode(tile))
+                if i > 0:
+                    tile = tile[:, :, 1:]
+                row.append(tile)
+            result = []
+            for i, tile in enumerate(row):
+                if i > 0:
+                    tile = self._blend(row[i - 1], tile, blend_extent, 2)
+                    result.append(tile[:, :, :t_limit])
+                else:
+                    result.append(tile[:, :, :t_limit + 1])
+            moments = torch.cat(result, dim=2)
+        elif self.use_hw_tiling and z.shape[2] > 1:
+            moments = self._hw_tiled_encode(z)
+        else:
+            moments = None
+            mu, logvar = self._encode(z, stats=_stats)
+        if moments is not None:
+            C = self.encoder.latent_channels
+            mu, logvar = moments[:, :C], (moments[:, C:] if moments.shape[1] > C else None)
+            if _stats is not None:
+                std, mean = _stats
+                mu = ((mu.float() - mean.view(1, -1, 1, 1, 1)) / std.view(1, -1, 1, 1, 1)).to(mu.dtype)
+        posterior = DiagonalGaussianDistribution(mu, logvar)
+        if not return_dict:
+            return (posterior,)
+        return AutoencoderKLOutput(latent_dist=posterior)
 
     # ---- decode ------------------------------------------------------------------------
     def _decode(self, z, target_shape=None, timestep=None, stats=None):          # vae.py:343-355
@@ -472,6 +718,33 @@ class CausalVideoAutoencoder(nn.Module):
         if not return_dict:
             return (decoded,)
         return DecoderOutput(sample=decoded)
+
+
+def vae_encode(media_items, vae: CausalVideoAutoencoder, split_size: int = 1, vae_per_channel_normalize=False,
+               generator: Optional[torch.Generator] = None, sample_posterior: bool = True):
+    """vae_encode.py:22-91: pixels [B,3,F,H,W] (or [B,3,H,W]) in [-1,1] -> normalised latents [B,C,f,h,w].
+    ``latent_dist.sample()`` as there (``sample_posterior=False`` takes the mode).  The per-channel
+    normalisation commutes with the sampling as (mean - m)/s + (std/s) * noise; it is folded into the
+    encoder's layout pass for the mean and applied to the noise term here."""
+    if media_items.dim() == 4:
+        media_items = media_items.unsqueeze(2)
+    if media_items.shape[1] != 3:
+        raise ValueError(f"Expects tensors with 3 channels, got {media_items.shape[1]}.")
+    if split_size != 1:
+        raise NotImplementedError("split_size > 1 is not on this path")
+    stats = None
+    if vae_per_channel_normalize:
+        stats = (vae.std_of_means.float().contiguous(), vae.mean_of_means.float().contiguous())
+    dist = vae.encode(media_items.to(vae.dtype), _stats=stats).latent_dist
+    scale = 1.0 if vae_per_channel_normalize else float(vae._config.get("scaling_factor", 1.0))
+    z = dist.mean.float() * scale
+    if sample_posterior and not dist.deterministic:
+        noise = torch.randn(z.shape, generator=generator, device=z.device, dtype=torch.float32)
+        s = dist.std * scale
+        if stats is not None:
+            s = s / stats[0].view(1, -1, 1, 1, 1)
+        z = z + s * noise
+    return z.to(vae.dtype)
 
 
 def vae_decode(latents, vae: CausalVideoAutoencoder, is_video: bool = True, split_size: int = 1,

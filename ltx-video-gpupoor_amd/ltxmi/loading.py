@@ -135,8 +135,8 @@ def load_transformer(path, device="cuda", dtype=torch.bfloat16):
     return model.eval()
 
 
-def load_vae(path, device="cuda", dtype=torch.bfloat16):
-    """Build the decode side of ``CausalVideoAutoencoder`` from a checkpoint."""
+def load_vae(path, device="cuda", dtype=torch.bfloat16, with_encoder=True):
+    """Build ``CausalVideoAutoencoder`` from a checkpoint (``with_encoder=False``: decode side only)."""
     from .autoencoder import CausalVideoAutoencoder
     path = str(path)
     if os.path.isdir(path):
@@ -152,13 +152,13 @@ def load_vae(path, device="cuda", dtype=torch.bfloat16):
         config = json.loads(meta["config"])["vae"]
     else:
         raise ValueError(f"unrecognised checkpoint path: {path}")
+    config["build_encoder"] = bool(with_encoder)
     vae = CausalVideoAutoencoder.from_config(config)
     if any(k.startswith("vae.") for k in sd):
         sd = {k.replace("vae.", "", 1): v for k, v in sd.items() if k.startswith("vae.")}
     want = vae.state_dict()
-    sd = {k: v for k, v in sd.items() if not k.startswith("encoder.")}
     missing = [k for k in want if k not in sd]
     if missing:
-        raise KeyError(f"checkpoint is missing decoder tensors: {missing[:5]} ...")
+        raise KeyError(f"checkpoint is missing VAE tensors: {missing[:5]} ...")
     vae.load_state_dict({k: v for k, v in sd.items() if k in want}, strict=True)
     return vae.to(device=device, dtype=dtype).eval()

@@ -213,26 +213,37 @@ def stg_blend_(a, v, m_f32):
     return a
 
 
-def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, add=None, out=None):
-    """x [B,T,H,W,Cin] NDHWC; w_packed [Cout, 27*Cin] (tap-major; (p1p2p3, c')-major rows when d2s)."""
+def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, add=None, out=None,
+           stride=(1, 1, 1), tpad=0, out_T=0):
+    """x [B,T,H,W,Cin] NDHWC; w_packed [Cout, 27*Cin] (tap-major; (p1p2p3, c')-major rows when d2s).
+    stride = (st, s, s) with st, s in {1, 2}; tpad / out_T: front time padding and output frames
+    when they differ from CausalConv3d's (0 = default), see include/ltxmi.h."""
     _chk_bf16(x, w_packed, bias, residual, add, out)
     B, T, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
     if not x.is_contiguous() or not w_packed.is_contiguous():
         raise ValueError("ltxmi.conv3d: x and w must be contiguous")
+    st, sh, sw = stride
+    if sh != sw:
+        raise ValueError("ltxmi.conv3d: height and width strides must be equal")
+    front = tpad if tpad > 0 else (2 if causal else 1)
+    back = 0 if (tpad > 0 or causal) else 1
+    oT = out_T if out_T > 0 else (T + front + back - 3) // st + 1
+    oH, oW = (H - 1) // sh + 1, (W - 1) // sh + 1
     if out is None:
         if d2s:
             out = torch.empty((B, 2 * T - 1, 2 * H, 2 * W, Cout // 8), dtype=BF16, device=x.device)
         else:
-            out = torch.empty((B, T, H, W, Cout), dtype=BF16, device=x.device)
+            out = torch.empty((B, oT, oH, oW, Cout), dtype=BF16, device=x.device)
     a = _lib.Conv3dArgs()
     a.x, a.w, a.bias, a.y = x.data_ptr(), w_packed.data_ptr(), (bias.data_ptr() if bias is not None else None), out.data_ptr()
     a.B, a.T, a.H, a.W, a.Cin, a.Cout = B, T, H, W, Cin, Cout
     a.causal, a.pad_replicate, a.d2s = int(causal), int(pad_replicate), int(d2s)
+    a.stride_t, a.stride_hw, a.tpad, a.out_T = st, sh, tpad, out_T
     if residual is not None:
         a.residual, a.res_channels = residual.data_ptr(), residual.shape[-1]
     if add is not None:
-        if not add.is_contiguous() or add.shape != (B, T, H, W, Cout):
+        if not add.is_contiguous() or add.shape != (B, oT, oH, oW, Cout):
             raise ValueError("ltxmi.conv3d: `add` must be a contiguous [B,T,H,W,Cout] tensor")
         a.add = add.data_ptr()
     check(lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), _stream()), "ltxmi_conv3d_ndhwc_bf16")
@@ -274,6 +285,43 @@ def unpatchify_to_ncdhw(x, c_out, patch):
     out = torch.empty((B, c_out, T, H * patch, W * patch), dtype=BF16, device=x.device)
     check(lib.ltxmi_unpatchify_to_ncdhw_bf16(_ptr(x), _ptr(out), B, T, H, W, c_out, patch, _stream()),
           "ltxmi_unpatchify_to_ncdhw_bf16")
+    return out
+
+
+def patchify_to_ndhwc(x, patch, c_pad):
+    """pixels [B,C,T,H,W] -> NDHWC [B,T,H/p,W/p,c_pad] (zero channels beyond C*p*p)."""
+    _chk_bf16(x)
+    B, C, T, H, W = x.shape
+    out = torch.empty((B, T, H // patch, W // patch, c_pad), dtype=BF16, device=x.device)
+    check(lib.ltxmi_patchify_to_ndhwc_bf16(_ptr(x.contiguous()), _ptr(out), B, C, T, H, W, patch, c_pad, _stream()),
+          "ltxmi_patchify_to_ndhwc_bf16")
+    return out
+
+
+def space_to_depth_skip(conv, x, stride):
+    """conv [B,T',H,W,Cc] (T' = T+1 when stride[0] == 2), x [B,T,H,W,Cin] -> [B,T'/st,H/s,W/s,Cc*st*s*s]."""
+    _chk_bf16(conv, x)
+    B, T, H, W, Cin = x.shape
+    Cc = conv.shape[-1]
+    st, s, _ = stride
+    Tc = T + 1 if st == 2 else T
+    if tuple(conv.shape) != (B, Tc, H, W, Cc) or not conv.is_contiguous() or not x.is_contiguous() or Cin % Cc:
+        raise ValueError(f"ltxmi.space_to_depth_skip: conv {tuple(conv.shape)} does not match x {tuple(x.shape)}")
+    out = torch.empty((B, Tc // st, H // s, W // s, Cc * st * s * s), dtype=BF16, device=x.device)
+    check(lib.ltxmi_space_to_depth_skip_bf16(_ptr(conv), _ptr(x), _ptr(out), B, T, H, W, Cin, Cc, st, s, Cin // Cc,
+                                             _stream()), "ltxmi_space_to_depth_skip_bf16")
+    return out
+
+
+def ndhwc_to_ncdhw(x, c0, C, std=None, mean=None):
+    """channels c0..c0+C of NDHWC x -> NCDHW [B,C,T,H,W], optionally (v - mean) / std per channel."""
+    _chk_bf16(x)
+    B, T, H, W, ld = x.shape
+    if not x.is_contiguous():
+        raise ValueError("ltxmi.ndhwc_to_ncdhw: x must be contiguous")
+    out = torch.empty((B, C, T, H, W), dtype=BF16, device=x.device)
+    check(lib.ltxmi_ndhwc_to_ncdhw_bf16(_ptr(x), ld, c0, _ptr(out), B, C, T, H, W, _ptr(std), _ptr(mean), _stream()),
+          "ltxmi_ndhwc_to_ncdhw_bf16")
     return out
 
 

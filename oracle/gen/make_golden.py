@@ -346,14 +346,82 @@ def g10():
         save(f"g10_decoder_{tag}", t, dict(cfg=cfg))
 
 
+@torch.no_grad()
+def g11():
+    """Encoder side: strided CausalConv3d, SpaceToDepthDownsample, Encoder.forward, _encode,
+    z-/hw-tiled encode and normalize_latents for both block plans.  The diffusers leaves
+    (DiagonalGaussianDistribution / AutoencoderKLOutput) are absent: encode() is run with them
+    replaced by identities so that it returns the moments tensor it would wrap."""
+    print("G11 encoder")
+    import ltx_video.models.autoencoders.vae as ref_vae
+    ref_vae.DiagonalGaussianDistribution = lambda moments: moments
+    ref_vae.AutoencoderKLOutput = lambda latent_dist: latent_dist
+    g = torch.Generator().manual_seed(60)
+    t = {}
+    xs = torch.randn(2, 8, 5, 6, 8, generator=g)
+    t["x"] = xs
+    for name, stride in (("time", (2, 1, 1)), ("space", (1, 2, 2)), ("all", (2, 2, 2))):
+        for mode in ("zeros", "replicate"):
+            torch.manual_seed(61)
+            conv = ref_cc3.CausalConv3d(8, 12, kernel_size=3, stride=stride, spatial_padding_mode=mode)
+            t[f"sconv.{name}.{mode}.conv.weight"], t[f"sconv.{name}.{mode}.conv.bias"] = conv.conv.weight, conv.conv.bias
+            t[f"sconv.{name}.{mode}.out"] = conv(xs, causal=True)
+        torch.manual_seed(62)
+        s2d = ref_cva.SpaceToDepthDownsample(dims=3, in_channels=8, out_channels=16, stride=stride,
+                                             spatial_padding_mode="replicate").eval()
+        xin = xs if stride[0] == 1 else xs[:, :, :5]          # T=5 -> 6 frames after the duplicated first one
+        t[f"s2d.{name}.out"] = s2d(xin)
+        for k, v in s2d.state_dict().items():
+            t[f"s2d.{name}.sd.{k}"] = v
+    save("g11_encoder_blocks", t)
+
+    for tag, cfg in (("a", jsonable(TINY_VAE_A)), ("b", jsonable(tiny_vae_b()))):
+        torch.manual_seed(63)
+        vae = ref_cva.CausalVideoAutoencoder.from_config(json.loads(json.dumps(cfg))).eval()
+        C = cfg["latent_channels"]
+        std = 0.5 + torch.rand(C, generator=g)
+        mean = 0.2 * torch.randn(C, generator=g)
+        vae.register_buffer("std_of_means", std)
+        vae.register_buffer("mean_of_means", mean)
+        t = {"per_channel_statistics.std-of-means": std, "per_channel_statistics.mean-of-means": mean}
+        for k, v in vae.state_dict().items():
+            if k.startswith("encoder."):
+                t["sd." + k] = v
+        x = torch.rand(1, 3, 9, 64, 32, generator=g) * 2 - 1
+        t["x"] = x
+        t["encoder"] = vae.encoder(x)
+        t["moments"] = vae.encode(x, return_dict=False)[0]
+        t["image_moments"] = vae.encode(x[:, :, :1], return_dict=False)[0]
+        t["normalized_mean"] = ref_ve.normalize_latents(t["moments"][:, :C], vae, vae_per_channel_normalize=True)
+        xz = torch.rand(1, 3, 41, 32, 32, generator=g) * 2 - 1
+        t["x_ztile"] = xz
+        vae.enable_z_tiling(4)
+        t["moments_ztile"] = vae.encode(xz, return_dict=False)[0]
+        vae.disable_z_tiling()
+        xh = torch.rand(1, 3, 9, 128, 160, generator=g).to(torch.bfloat16)    # stored as bf16 (size)
+        t["x_hwtile"] = xh
+        vae.set_tiling_params(sample_size=128, overlap_factor=0.25)
+        vae.enable_hw_tiling()
+        t["moments_hwtile"] = vae.encode(xh.float(), return_dict=False)[0]
+        vae.disable_hw_tiling()
+        save(f"g11_encoder_{tag}", t, dict(cfg=cfg))
+
+
+CASES = {"g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11}
+
+
 def main():
+    """No arguments: regenerate everything.  With case names (``g11`` ...): only those, merged
+    into the existing manifest."""
     os.makedirs(OUT, exist_ok=True)
-    g1_g2()
-    g3_g4_g5()
-    g6()
-    g8_g9()
-    g10()
-    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+    names = sys.argv[1:] or list(CASES)
+    mpath = os.path.join(OUT, "manifest.json")
+    if sys.argv[1:] and os.path.exists(mpath):
+        with open(mpath) as f:
+            MANIFEST.update(json.load(f))
+    for n in names:
+        CASES[n]()
+    with open(mpath, "w") as f:
         json.dump(MANIFEST, f, indent=1, default=list)
     print("done")
 

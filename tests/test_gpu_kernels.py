@@ -360,3 +360,58 @@ def test_guidance_step(cfg, stg, resc, lat_dtype):
         torch.testing.assert_close(d.cpu(), truth, rtol=2e-4, atol=2e-5)
     else:
         check(d, truth, what="guidance bf16 latents")
+
+
+# ------------------------------------------------------------------- encoder-side kernels
+@pytest.mark.parametrize("stride", [(2, 1, 1), (1, 2, 2), (2, 2, 2)])
+@pytest.mark.parametrize("mode", ["zeros", "replicate"])
+@pytest.mark.parametrize("cin,cout,shape", [(64, 128, (1, 5, 6, 8)), (128, 72, (2, 4, 5, 7))])
+def test_conv3d_strided(stride, mode, cin, cout, shape):
+    """Strided causal convolutions of the encoder's compress_* blocks (odd and even extents)."""
+    from ltxmi import ops
+    from oracle import vae_encoder as oe
+    B, T, H, W = shape
+    x = rnd(B, cin, T, H, W, seed=70)
+    w = rnd(cout, cin, 3, 3, 3, seed=71, scale=(27 * cin) ** -0.5)
+    b = rnd(cout, seed=72)
+    truth = oe.strided_causal_conv3d(x.float(), {"conv.weight": w.float(), "conv.bias": b.float()}, "", stride, mode)
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
+    out = ops.conv3d(ndhwc(x).to(DEV), wp.to(DEV), b.to(DEV), True, mode == "replicate", stride=stride)
+    assert ncdhw(out.cpu()).shape == truth.shape
+    check(ncdhw(out.cpu()), truth, what=f"strided conv3d {stride} {mode} {cin}->{cout}")
+
+
+@pytest.mark.parametrize("stride,cin,cout", [((2, 1, 1), 64, 128), ((1, 2, 2), 64, 128), ((2, 2, 2), 64, 128),
+                                              ((2, 2, 2), 128, 128)])
+def test_space_to_depth_downsample(stride, cin, cout):
+    from ltxmi import autoencoder as ae
+    from oracle import vae_encoder as oe
+    blk = ae.SpaceToDepthDownsample(3, cin, cout, stride, "replicate").to(BF)
+    sd = {k: v.detach().float() for k, v in blk.state_dict().items()}
+    T = 5 if stride[0] == 2 else 4
+    x = rnd(2, cin, T, 4, 6, seed=73)
+    prod = stride[0] * stride[1] * stride[2]
+    truth = oe.space_to_depth_downsample(x.float(), sd, "", dict(stride=stride, group=cin * prod // cout), "replicate")
+    out = blk.to(DEV)(ndhwc(x).to(DEV))
+    assert ncdhw(out.cpu()).shape == truth.shape
+    check(ncdhw(out.cpu()), truth, what=f"space-to-depth {stride} {cin}->{cout}")
+
+
+def test_patchify_and_ndhwc_to_ncdhw():
+    """Layout kernels are exact (bit copies; the normalisation is one fp32 op)."""
+    from ltxmi import ops
+    from oracle import vae as ov
+    x = rnd(2, 3, 3, 8, 12, seed=74)
+    out = ops.patchify_to_ndhwc(x.to(DEV), 4, 64).cpu()
+    truth = ov.patchify(x, 4, 1)                                   # [B,48,T,2,3]
+    assert out.shape == (2, 3, 2, 3, 64)
+    assert torch.equal(ncdhw(out)[:, :48], truth) and not out[..., 48:].any()
+    y = rnd(2, 2, 3, 4, 136, seed=75)                              # NDHWC rows with a padded channel count
+    std, mean = torch.rand(128) + 0.5, torch.randn(128) * 0.2
+    got = ops.ndhwc_to_ncdhw(y.to(DEV), 0, 128).cpu()
+    assert torch.equal(got, ncdhw(y)[:, :128])
+    got = ops.ndhwc_to_ncdhw(y.to(DEV), 128, 1).cpu()
+    assert torch.equal(got, ncdhw(y)[:, 128:129])
+    got = ops.ndhwc_to_ncdhw(y.to(DEV), 0, 128, std.to(DEV), mean.to(DEV)).cpu()
+    want = ((ncdhw(y)[:, :128].float() - mean.view(1, -1, 1, 1, 1)) / std.view(1, -1, 1, 1, 1))
+    check(got, want, what="normalize_latents layout pass")

@@ -167,8 +167,9 @@ def test_transformer_2b_width_two_layers():
 
 
 # ------------------------------------------------------------------------------- VAE
-def vae_case(style, base=64, latent=128, seed=0):
+def vae_case(style, base=64, latent=128, seed=0, with_encoder=False):
     from oracle import vae as ov
+    from oracle import vae_encoder as oe
     if style == "b":
         cfg = ov.demo_config(latent)
     else:
@@ -179,8 +180,14 @@ def vae_case(style, base=64, latent=128, seed=0):
                "scaling_factor": 1.0, "norm_layer": "pixel_norm", "patch_size": 4, "latent_log_var": "uniform",
                "use_quant_conv": False, "causal_decoder": False}
     cfg["decoder_base_channels"] = base
-    sd = {k: (v.to(BF).float() if v.is_floating_point() and v.dim() > 0 else v)
-          for k, v in ov.init_state_dict(cfg, seed=seed).items()}
+    cfg["build_encoder"] = with_encoder
+    raw = dict(ov.init_state_dict(cfg, seed=seed))
+    if with_encoder:
+        cfg["encoder_base_channels"] = base
+        if style == "b":
+            cfg["encoder_blocks"] = oe.demo_encoder_blocks()
+        raw.update(oe.init_state_dict(cfg, seed=seed + 1))
+    sd = {k: (v.to(BF).float() if v.is_floating_point() and v.dim() > 0 else v) for k, v in raw.items()}
     return cfg, sd
 
 
@@ -241,6 +248,62 @@ def test_vae_tiled_decode_matches_oracle_tiling():
     v.disable_hw_tiling()
     assert out.shape == truth.shape
     assert rel(out, truth) < 2e-2
+
+
+@pytest.mark.parametrize("style", ["a", "b"])
+def test_vae_encode(style):
+    """Encoder.forward + encode + vae_encode (conditioning path) vs the oracle, both block plans
+    (a: strided compress_all + res_x_y; b: space-to-depth residual downsamples)."""
+    from oracle import vae_encoder as oe
+    import ltxmi
+    cfg, sd = vae_case(style, with_encoder=True)
+    g = torch.Generator().manual_seed(12)
+    x = (torch.rand(1, 3, 9, 64, 96, generator=g) * 2 - 1).to(BF)
+    truth = oe.encode(sd, cfg, x.float())                                    # moments [1, 256, 2, 2, 3]
+    sdb = {k: (v.to(BF) if v.is_floating_point() and v.dim() > 0 else v) for k, v in sd.items()}
+    eager = oe.encode(sdb, cfg, x)
+    v = build_vae(cfg, sd)
+    dist = v.encode(x.to(DEV)).latent_dist
+    assert isinstance(dist, ltxmi.DiagonalGaussianDistribution)
+    out = dist.parameters
+    assert out.shape == truth.shape == (1, 256, 2, 2, 3)
+    e_ours, e_ref = rel(out, truth), rel(eager, truth)
+    print(f"vae encode {style}: ours {e_ours:.3e}  reference-bf16-eager {e_ref:.3e}")
+    assert torch.isfinite(out).all()
+    assert e_ours <= e_ref + RTOL, (e_ours, e_ref)
+    # vae_encode: mode (no sampling) == normalised mean; sampling adds std/s * noise
+    want = oe.vae_encode(sd, cfg, x.float())
+    got = ltxmi.vae_encode(x.to(DEV), v, vae_per_channel_normalize=True, sample_posterior=False)
+    assert got.dtype == BF and rel(got, want) <= e_ref + 2 * RTOL
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    noise = torch.randn(want.shape, generator=torch.Generator(device=DEV).manual_seed(3), device=DEV)
+    want_s = oe.vae_encode(sd, cfg, x.float(), noise=noise.cpu())
+    got_s = ltxmi.vae_encode(x.to(DEV), v, vae_per_channel_normalize=True, generator=gen)
+    assert rel(got_s, want_s) <= e_ref + 2 * RTOL
+    # a single image (F = 1) goes through the same causal path
+    truth1 = oe.encode(sd, cfg, x[:, :, :1].float())
+    out1 = v.encode(x[:, :, :1].to(DEV)).latent_dist.parameters
+    assert out1.shape == truth1.shape and rel(out1, truth1) <= rel(oe.encode(sdb, cfg, x[:, :, :1]), truth1) + RTOL
+
+
+def test_vae_tiled_encode_matches_oracle_tiling():
+    from oracle import vae_encoder as oe
+    cfg, sd = vae_case("b", with_encoder=True)
+    v = build_vae(cfg, sd)
+    g = torch.Generator().manual_seed(13)
+    x = (torch.rand(1, 3, 41, 32, 32, generator=g) * 2 - 1).to(BF)
+    truth = oe.encode(sd, cfg, x.float(), use_z_tiling=True, z_sample_size=4)
+    v.enable_z_tiling(4)
+    out = v.encode(x.to(DEV)).latent_dist.parameters
+    v.disable_z_tiling()
+    assert out.shape == truth.shape and rel(out, truth) < 2e-2
+    x = (torch.rand(1, 3, 9, 128, 160, generator=g) * 2 - 1).to(BF)
+    truth = oe.encode(sd, cfg, x.float(), use_hw_tiling=True, tile_sample_min_size=128)
+    v.set_tiling_params(sample_size=128, overlap_factor=0.25)
+    v.enable_hw_tiling()
+    out = v.encode(x.to(DEV)).latent_dist.parameters
+    v.disable_hw_tiling()
+    assert out.shape == truth.shape and rel(out, truth) < 2e-2
 
 
 # ------------------------------------------------------------------------ denoise loop

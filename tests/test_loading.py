@@ -60,3 +60,24 @@ def test_vae_single_file_and_diffusers_key_map(tmp_path):
                          "latents_std": 2}, loading.VAE_KEYS_RENAME)
     assert set(r) == {"decoder.up_blocks.0.res_blocks.0.conv1.conv.weight", "decoder.up_blocks.2.conv.conv.weight",
                       "per_channel_statistics.std-of-means"}
+
+
+def test_vae_single_file_with_encoder(tmp_path):
+    """Encoder tensors load under the reference's key names (encoder.down_blocks.N....)."""
+    from ltxmi import CausalVideoAutoencoder
+    from oracle import vae_encoder as oe
+    cfg = ov.demo_config(128)
+    cfg["decoder_base_channels"] = 64
+    cfg["encoder_blocks"] = oe.demo_encoder_blocks()
+    cfg["encoder_base_channels"] = 64
+    sd = dict(ov.init_state_dict(cfg, seed=1))
+    sd.update(oe.init_state_dict(cfg, seed=2))
+    blob = {"vae." + k: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k, v in sd.items()}
+    path = os.path.join(tmp_path, "vae.safetensors")
+    save_file(blob, path, metadata={"config": json.dumps({"vae": cfg})})
+    v = CausalVideoAutoencoder.from_pretrained(path, device="cpu")
+    got = v.state_dict()
+    assert any(k.startswith("encoder.down_blocks.1.conv.conv.") for k in got)
+    for k in sd:
+        assert k in got and got[k].shape == sd[k].shape, k
+    assert set(got) == set(sd)

@@ -199,3 +199,42 @@ def test_guidance_math_properties():
     # (do_rescaling False when all scales are 1.0 in the reference; force the formula)
     out = sched.guidance(n, 3, 3.0, 1.0, 0.999999, True, True, True)
     torch.testing.assert_close(out.std(), n[1].std(), rtol=1e-3, atol=1e-4)
+
+
+def test_g11_encoder_blocks(golden):
+    """Strided CausalConv3d (causal_conv3d.py:33-57) and SpaceToDepthDownsample (:976-1020)."""
+    from oracle import vae_encoder as ve
+    t, _ = golden("g11_encoder_blocks")
+    for name, stride in (("time", (2, 1, 1)), ("space", (1, 2, 2)), ("all", (2, 2, 2))):
+        for mode in ("zeros", "replicate"):
+            out = ve.strided_causal_conv3d(t["x"], sub(t, f"sconv.{name}.{mode}."), "", stride, mode)
+            torch.testing.assert_close(out, t[f"sconv.{name}.{mode}.out"], **TOL)
+        blk = dict(stride=stride, group=8 * stride[0] * stride[1] * stride[2] // 16)
+        out = ve.space_to_depth_downsample(t["x"], sub(t, f"s2d.{name}.sd."), "", blk, "replicate")
+        torch.testing.assert_close(out, t[f"s2d.{name}.out"], **TOL)
+
+
+def _encoder_case(golden, tag):
+    from oracle import vae_encoder as ve
+    t, meta = golden(f"g11_encoder_{tag}")
+    cfg = meta["cfg"]
+    sd = sub(t, "sd.")
+    sd["per_channel_statistics.std-of-means"] = t["per_channel_statistics.std-of-means"]
+    sd["per_channel_statistics.mean-of-means"] = t["per_channel_statistics.mean-of-means"]
+    tol = dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ve.encoder_forward(sd, cfg, t["x"]), t["encoder"], **tol)
+    torch.testing.assert_close(ve.encode(sd, cfg, t["x"]), t["moments"], **tol)
+    torch.testing.assert_close(ve.encode(sd, cfg, t["x"][:, :, :1]), t["image_moments"], **tol)
+    torch.testing.assert_close(ve.vae_encode(sd, cfg, t["x"]), t["normalized_mean"], **tol)
+    out = ve.encode(sd, cfg, t["x_ztile"], use_z_tiling=True, z_sample_size=4)
+    torch.testing.assert_close(out, t["moments_ztile"], **tol)
+    out = ve.encode(sd, cfg, t["x_hwtile"].float(), use_hw_tiling=True, tile_sample_min_size=128)
+    torch.testing.assert_close(out, t["moments_hwtile"], **tol)
+
+
+def test_g11_encoder_plan_a_strided(golden):
+    _encoder_case(golden, "a")
+
+
+def test_g11_encoder_plan_b_space_to_depth(golden):
+    _encoder_case(golden, "b")
