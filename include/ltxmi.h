@@ -241,6 +241,25 @@ int ltxmi_guidance_step_bf16(const void* noise_pred, int64_t n, int32_t num_cond
                              void* latents, int32_t latents_bf16, float dt, float* workspace,
                              void* stream);
 
+/* The same step when conditioning items are present (image-/video-to-video):
+ * denoising_step, pipeline_ltx_video.py:1309-1342 -- token i (of `channels` values each) is
+ * advanced only if t - 1e-6 < 1 - cond_mask[i]; hard-conditioned tokens (mask 1) never move.
+ * cond_mask: fp32 [n / channels] or NULL (= ltxmi_guidance_step_bf16).  For the tokens that do
+ * move, their per-token timestep min(t, 1 - mask) equals t, so dt is the global step. */
+int ltxmi_guidance_step_masked_bf16(const void* noise_pred, int64_t n, int32_t num_conds,
+                                    float guidance_scale, float stg_scale, float rescaling_scale,
+                                    int32_t do_cfg, int32_t do_stg, int32_t do_rescale,
+                                    void* latents, int32_t latents_bf16, float dt,
+                                    const float* cond_mask, int32_t channels, float t,
+                                    float* workspace, void* stream);
+
+/* add_noise_to_image_conditioning_latents, pipeline_ltx_video.py:606-629: tokens with
+ * cond_mask > 1 - 1e-6 become init_latents + noise_scale * noise * t^2, others are untouched.
+ * latents / init_latents / noise: [tokens, channels], all fp32 (is_bf16 = 0) or all bf16 (= 1). */
+int ltxmi_image_cond_noise(void* latents, const void* init_latents, const void* noise, int32_t is_bf16,
+                           const float* cond_mask, int64_t tokens, int32_t channels, float noise_scale,
+                           float t, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -173,6 +173,7 @@ struct GuidanceP {
     const uint16_t* np; int64_t n; int num_conds;
     float gs, stg, rs; int do_cfg, do_stg, do_rescale;
     float* lat_f32; uint16_t* lat_bf16; float dt; float* ws;
+    const float* cond_mask; int channels; float t;      // conditioning: token n steps iff t - 1e-6 < 1 - cond_mask[n]
 };
 
 // block sum through LDS, then ONE float atomic per block and value (256 blocks at most: the
@@ -252,8 +253,21 @@ __global__ void guidance_apply(GuidanceP p) {
         // the reference holds noise_pred in bf16 after the guidance arithmetic; the Euler
         // update itself runs in the latents' dtype (rf.py:375)
         const float o = guidance_combine(p, u, t, q, alpha) * factor;
+        if (p.cond_mask && !(p.t - 1e-6f < 1.0f - p.cond_mask[i / p.channels])) continue;   // :1341-1342
         if (p.lat_f32) p.lat_f32[i] = p.lat_f32[i] - p.dt * o;
         else p.lat_bf16[i] = f2bf(bf2f(p.lat_bf16[i]) - p.dt * o);
+    }
+}
+
+// add_noise_to_image_conditioning_latents (pipeline_ltx_video.py:606-629): hard-conditioned tokens
+// (mask > 1 - eps) are reset to init + noise_scale * noise * t^2, the others keep their value
+template <typename T>
+__global__ void cond_noise_kernel(T* __restrict__ lat, const T* __restrict__ init, const T* __restrict__ noise,
+                                  const float* __restrict__ mask, int channels, float scale_t2, int64_t total) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!(mask[i / channels] > 1.0f - 1e-6f)) continue;
+        if constexpr (sizeof(T) == 4) lat[i] = init[i] + scale_t2 * noise[i];
+        else lat[i] = f2bf(bf2f(init[i]) + scale_t2 * bf2f(noise[i]));
     }
 }
 
@@ -323,10 +337,11 @@ extern "C" int ltxmi_unpatchify_to_ncdhw_bf16(const void* x, void* y, int32_t B,
     return check_launch("ltxmi_unpatchify_to_ncdhw_bf16");
 }
 
-extern "C" int ltxmi_guidance_step_bf16(const void* noise_pred, int64_t n, int32_t num_conds, float guidance_scale,
-                                        float stg_scale, float rescaling_scale, int32_t do_cfg, int32_t do_stg,
-                                        int32_t do_rescale, void* latents, int32_t latents_bf16, float dt,
-                                        float* workspace, void* stream) {
+extern "C" int ltxmi_guidance_step_masked_bf16(const void* noise_pred, int64_t n, int32_t num_conds,
+                                               float guidance_scale, float stg_scale, float rescaling_scale,
+                                               int32_t do_cfg, int32_t do_stg, int32_t do_rescale, void* latents,
+                                               int32_t latents_bf16, float dt, const float* cond_mask,
+                                               int32_t channels, float t, float* workspace, void* stream) {
     LTXMI_REQUIRE(noise_pred && latents && workspace, LTXMI_ERR_INVALID_ARG, "ltxmi_guidance_step_bf16: NULL argument");
     LTXMI_REQUIRE(n > 1, LTXMI_ERR_INVALID_ARG, "ltxmi_guidance_step_bf16: n must be > 1");
     LTXMI_REQUIRE(num_conds == 1 + (do_cfg ? 1 : 0) + (do_stg ? 1 : 0), LTXMI_ERR_INVALID_ARG,
@@ -339,6 +354,9 @@ extern "C" int ltxmi_guidance_step_bf16(const void* noise_pred, int64_t n, int32
     p.lat_f32 = latents_bf16 ? nullptr : (float*)latents;
     p.lat_bf16 = latents_bf16 ? (uint16_t*)latents : nullptr;
     p.dt = dt; p.ws = workspace;
+    p.cond_mask = cond_mask; p.channels = channels > 0 ? channels : 1; p.t = t;
+    LTXMI_REQUIRE(!cond_mask || (channels > 0 && n % channels == 0), LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_guidance_step_bf16: n=%lld is not a multiple of channels=%d", (long long)n, channels);
     if (hipMemsetAsync(workspace, 0, 8 * sizeof(float), s) != hipSuccess) {
         set_error("ltxmi_guidance_step_bf16: hipMemsetAsync failed");
         return LTXMI_ERR_LAUNCH;
@@ -349,6 +367,31 @@ extern "C" int ltxmi_guidance_step_bf16(const void* noise_pred, int64_t n, int32
     hipLaunchKernelGGL(guidance_reduce2, dim3(g), dim3(PW_THREADS), 0, s, p);
     hipLaunchKernelGGL(guidance_apply, dim3(g), dim3(PW_THREADS), 0, s, p);
     return check_launch("ltxmi_guidance_step_bf16");
+}
+
+extern "C" int ltxmi_guidance_step_bf16(const void* noise_pred, int64_t n, int32_t num_conds, float guidance_scale,
+                                        float stg_scale, float rescaling_scale, int32_t do_cfg, int32_t do_stg,
+                                        int32_t do_rescale, void* latents, int32_t latents_bf16, float dt,
+                                        float* workspace, void* stream) {
+    return ltxmi_guidance_step_masked_bf16(noise_pred, n, num_conds, guidance_scale, stg_scale, rescaling_scale, do_cfg,
+                                           do_stg, do_rescale, latents, latents_bf16, dt, nullptr, 0, 0.f, workspace,
+                                           stream);
+}
+
+extern "C" int ltxmi_image_cond_noise(void* latents, const void* init_latents, const void* noise, int32_t is_bf16,
+                                      const float* cond_mask, int64_t tokens, int32_t channels, float noise_scale,
+                                      float t, void* stream) {
+    LTXMI_REQUIRE(latents && init_latents && noise && cond_mask, LTXMI_ERR_INVALID_ARG, "ltxmi_image_cond_noise: NULL argument");
+    LTXMI_REQUIRE(tokens > 0 && channels > 0, LTXMI_ERR_INVALID_ARG, "ltxmi_image_cond_noise: non-positive size");
+    const int64_t total = tokens * channels;
+    const float s = noise_scale * t * t;
+    if (is_bf16)
+        hipLaunchKernelGGL(cond_noise_kernel<uint16_t>, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                           (uint16_t*)latents, (const uint16_t*)init_latents, (const uint16_t*)noise, cond_mask, channels, s, total);
+    else
+        hipLaunchKernelGGL(cond_noise_kernel<float>, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                           (float*)latents, (const float*)init_latents, (const float*)noise, cond_mask, channels, s, total);
+    return check_launch("ltxmi_image_cond_noise");
 }
 
 extern "C" int ltxmi_patchify_to_ndhwc_bf16(const void* x, void* y, int32_t B, int32_t C, int32_t T, int32_t H,

@@ -62,6 +62,11 @@ SIGNATURES = {
                                           c_void_p, c_void_p]),
     "ltxmi_unpatchify_to_ncdhw_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                c_void_p]),
+    "ltxmi_guidance_step_masked_bf16": (c_int, [c_void_p, c_int64, c_int, c_float, c_float, c_float, c_int, c_int,
+                                                c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p,
+                                                c_void_p]),
+    "ltxmi_image_cond_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_float,
+                                       c_float, c_void_p]),
     "ltxmi_patchify_to_ndhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                              c_void_p]),
     "ltxmi_space_to_depth_skip_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

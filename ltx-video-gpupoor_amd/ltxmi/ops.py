@@ -326,15 +326,44 @@ def ndhwc_to_ncdhw(x, c0, C, std=None, mean=None):
 
 
 def guidance_step_(noise_pred, latents, dt, guidance_scale, stg_scale, rescaling_scale, do_cfg, do_stg, do_rescale,
-                   workspace):
-    """noise_pred bf16 [num_conds, N, C] (one sample); latents fp32/bf16 [1, N, C], updated in place."""
+                   workspace, cond_mask=None, t=0.0):
+    """noise_pred bf16 [num_conds, N, C] (one sample); latents fp32/bf16 [1, N, C], updated in place.
+    cond_mask fp32 [1, N] (or None): only tokens with t - 1e-6 < 1 - cond_mask are advanced."""
     _chk_bf16(noise_pred)
     num_conds = noise_pred.shape[0]
     n = noise_pred[0].numel()
     is_bf16 = latents.dtype == BF16
     if not is_bf16 and latents.dtype != torch.float32:
         raise TypeError("ltxmi.guidance_step_: latents must be fp32 or bf16")
-    check(lib.ltxmi_guidance_step_bf16(_ptr(noise_pred), n, num_conds, guidance_scale, stg_scale, rescaling_scale,
-                                       int(do_cfg), int(do_stg), int(do_rescale), _ptr(latents), int(is_bf16),
-                                       float(dt), _ptr(workspace), _stream()), "ltxmi_guidance_step_bf16")
+    if not latents.is_contiguous() or latents.numel() != n:
+        raise ValueError("ltxmi.guidance_step_: latents must be contiguous and match one chunk of noise_pred")
+    if cond_mask is None:
+        check(lib.ltxmi_guidance_step_bf16(_ptr(noise_pred), n, num_conds, guidance_scale, stg_scale, rescaling_scale,
+                                           int(do_cfg), int(do_stg), int(do_rescale), _ptr(latents), int(is_bf16),
+                                           float(dt), _ptr(workspace), _stream()), "ltxmi_guidance_step_bf16")
+        return latents
+    C = noise_pred.shape[-1]
+    if cond_mask.dtype != torch.float32 or not cond_mask.is_contiguous() or cond_mask.numel() * C != n:
+        raise ValueError("ltxmi.guidance_step_: cond_mask must be contiguous fp32 with one value per token")
+    check(lib.ltxmi_guidance_step_masked_bf16(_ptr(noise_pred), n, num_conds, guidance_scale, stg_scale,
+                                              rescaling_scale, int(do_cfg), int(do_stg), int(do_rescale),
+                                              _ptr(latents), int(is_bf16), float(dt), _ptr(cond_mask), C, float(t),
+                                              _ptr(workspace), _stream()), "ltxmi_guidance_step_masked_bf16")
+    return latents
+
+
+def image_cond_noise_(latents, init_latents, noise, cond_mask, noise_scale, t):
+    """latents/init_latents/noise [1, N, C] (all fp32 or all bf16), cond_mask fp32 [1, N]; in place."""
+    is_bf16 = latents.dtype == BF16
+    for x in (latents, init_latents, noise):
+        if x.dtype != latents.dtype or x.shape != latents.shape or not x.is_contiguous():
+            raise ValueError("ltxmi.image_cond_noise_: latents, init_latents and noise must match and be contiguous")
+    if latents.dtype not in (BF16, torch.float32) or cond_mask.dtype != torch.float32 or not cond_mask.is_contiguous():
+        raise TypeError("ltxmi.image_cond_noise_: fp32/bf16 latents and a contiguous fp32 mask expected")
+    C = latents.shape[-1]
+    tokens = latents.numel() // C
+    if cond_mask.numel() != tokens:
+        raise ValueError("ltxmi.image_cond_noise_: one mask value per token expected")
+    check(lib.ltxmi_image_cond_noise(_ptr(latents), _ptr(init_latents), _ptr(noise), int(is_bf16), _ptr(cond_mask),
+                                     tokens, C, float(noise_scale), float(t), _stream()), "ltxmi_image_cond_noise")
     return latents

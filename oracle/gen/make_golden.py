@@ -407,7 +407,102 @@ def g11():
         save(f"g11_encoder_{tag}", t, dict(cfg=cfg))
 
 
-CASES = {"g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11}
+@torch.no_grad()
+def g12():
+    """Conditioning-token assembly and the masked denoising step, run through the reference's own
+    LTXVideoPipeline methods on an instance created WITHOUT __init__ (no text encoder / transformer
+    needed for these methods).  The diffusers leaves are stand-ins: DiagonalGaussianDistribution.sample()
+    returns the mean (the reference draws unseeded noise there), randn_tensor is torch.randn and its
+    draws are recorded so that the oracle/product can be fed the same noise."""
+    print("G12 conditioning")
+    ref_shims.install_pipeline_leaves()
+    import ltx_video.pipelines.pipeline_ltx_video as ref_pl
+    import ltx_video.models.autoencoders.vae as ref_vae
+
+    class _Dist:
+        def __init__(self, moments):
+            self.mean = moments[:, : moments.shape[1] // 2]
+
+        def sample(self):
+            return self.mean
+
+    ref_vae.DiagonalGaussianDistribution = _Dist
+    ref_vae.AutoencoderKLOutput = lambda latent_dist: types.SimpleNamespace(latent_dist=latent_dist)
+    draws = []
+
+    def logged_randn(shape, generator=None, device=None, dtype=None, layout=None):
+        n = ref_shims.randn_tensor(shape, generator=generator, device=device, dtype=dtype)
+        draws.append(n)
+        return n
+
+    ref_pl.randn_tensor = logged_randn
+
+    cfg = jsonable(tiny_vae_b())
+    torch.manual_seed(63)          # same construction + seed as g11 "b": the encoder weights live in g11_encoder_b
+    vae = ref_cva.CausalVideoAutoencoder.from_config(json.loads(json.dumps(cfg))).eval()
+    g = torch.Generator().manual_seed(71)
+    C = cfg["latent_channels"]
+    std = 0.5 + torch.rand(C, generator=g)
+    mean = 0.2 * torch.randn(C, generator=g)
+    vae.register_buffer("std_of_means", std)
+    vae.register_buffer("mean_of_means", mean)
+    t = {"per_channel_statistics.std-of-means": std, "per_channel_statistics.mean-of-means": mean}
+    t["weights_check"] = vae.state_dict()["encoder.conv_out.conv.weight"]
+    pipe = object.__new__(ref_pl.LTXVideoPipeline)
+    pipe.vae = vae
+    pipe.patchifier = ref_sp.SymmetricPatchifier(patch_size=1)
+    pipe.vae_scale_factor = 32
+    pipe.transformer = types.SimpleNamespace(config=types.SimpleNamespace(causal_temporal_positioning=True),
+                                             use_tpu_flash_attention=False)
+    H, W, F_ = 64, 96, 33
+    img = torch.rand(1, 3, 1, H, W, generator=g) * 2 - 1
+    seq = torch.rand(1, 3, 17, H, W, generator=g) * 2 - 1
+    single = torch.rand(1, 3, 1, H, W, generator=g) * 2 - 1
+    t["img"], t["seq"], t["single"] = img, seq, single
+    items = [ref_pl.ConditioningItem(img, 0, 1.0), ref_pl.ConditioningItem(seq, 8, 0.9),
+             ref_pl.ConditioningItem(single, 24, 0.7)]
+    init = torch.randn(1, C, 5, 2, 3, generator=g)
+    t["init_latents"] = init.clone()
+    gen = torch.Generator().manual_seed(72)
+    lat, pc, mask, n_extra = pipe.prepare_conditioning(items, init, F_, H, W, vae_per_channel_normalize=True,
+                                                       generator=gen)
+    t["latents"], t["pixel_coords"], t["mask"] = lat, pc, mask
+    for i, n in enumerate(draws):
+        t[f"noise.{i}"] = n
+    n_draws = len(draws)
+    # no conditioning items: plain patchify + coords
+    lat0, pc0, mask0, n0 = pipe.prepare_conditioning(None, t["init_latents"].clone(), F_, H, W, vae_per_channel_normalize=True)
+    assert mask0 is None and n0 == 0
+    t["plain.latents"], t["plain.pixel_coords"] = lat0, pc0
+    # spatial placement of a smaller first-frame item (strip_latent_border)
+    small = ref_pl.ConditioningItem(torch.zeros(1, 3, 1, 64, 64), 0, 1.0, media_x=32, media_y=None)
+    zl = torch.randn(1, C, 1, 2, 2, generator=g)
+    out, lx, ly = pipe._get_latent_spatial_position(zl, small, 128, 160, strip_latent_border=True)
+    t["place.in"], t["place.out"] = zl, out.contiguous()
+    # image-conditioning noise + masked denoising step with the reference scheduler
+    sch = ref_rf.RectifiedFlowScheduler(num_train_timesteps=1000, shifting="SD3", base_resolution=None,
+                                        target_shift_terminal=0.1)
+    sch.set_timesteps(8, samples_shape=torch.Size((1, C, 5, 2, 3)), device="cpu")
+    pipe.scheduler = sch
+    t["timesteps"] = sch.timesteps
+    tt = sch.timesteps[3]
+    gen2 = torch.Generator().manual_seed(73)
+    cur = torch.randn(lat.shape, generator=g)
+    t["cur_latents"] = cur
+    noised = ref_pl.LTXVideoPipeline.add_noise_to_image_conditioning_latents(tt, lat, cur, 0.15, mask, gen2)
+    t["noised"], t["noise.cond"] = noised, draws[n_draws]
+    v = torch.randn(lat.shape, generator=g)
+    t["v"] = v
+    num_conds = 3
+    cur_t = tt[None].expand(num_conds).unsqueeze(-1)
+    cur_t = torch.min(cur_t, 1.0 - torch.cat([mask] * num_conds))
+    t["per_token_timestep"] = cur_t
+    t["stepped"] = pipe.denoising_step(noised, v, cur_t[:1], mask, tt, {})
+    save("g12_conditioning", t, dict(cfg=cfg, n_extra=int(n_extra), place=[int(lx), int(ly)], H=H, W=W, F=F_,
+                                     step_index=3, n_prepare_draws=n_draws))
+
+
+CASES = {"g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
 
 
 def main():

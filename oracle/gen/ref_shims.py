@@ -220,3 +220,23 @@ def install():
     u.__path__ = []
     _mod("diffusers.utils.torch_utils", maybe_allow_in_graph=lambda c: c,
          randn_tensor=None)
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
+    """diffusers.utils.torch_utils.randn_tensor, single-generator case: torch.randn on the
+    generator's device (restated leaf, PARITY UNPINNED like the other diffusers leaves)."""
+    return torch.randn(tuple(shape), generator=generator, device=device, dtype=dtype)
+
+
+def install_pipeline_leaves():
+    """Extra inert leaves so that ``ltx_video.pipelines.pipeline_ltx_video`` imports: its
+    static/helper methods (prepare_conditioning, denoising_step, add_noise_to_image_conditioning_latents,
+    the latent upsampler bridge ...) are then callable with a light stand-in ``self``."""
+    install()
+    _mod("diffusers.image_processor", VaeImageProcessor=_Dummy)
+    p = _mod("diffusers.pipelines")
+    p.__path__ = []
+    _mod("diffusers.pipelines.pipeline_utils", DiffusionPipeline=type("DiffusionPipeline", (), {}),
+         ImagePipelineOutput=_Dummy)
+    sys.modules["diffusers.schedulers"].DPMSolverMultistepScheduler = _Dummy
+    sys.modules["diffusers.utils.torch_utils"].randn_tensor = randn_tensor

@@ -415,3 +415,54 @@ def test_patchify_and_ndhwc_to_ncdhw():
     got = ops.ndhwc_to_ncdhw(y.to(DEV), 0, 128, std.to(DEV), mean.to(DEV)).cpu()
     want = ((ncdhw(y)[:, :128].float() - mean.view(1, -1, 1, 1, 1)) / std.view(1, -1, 1, 1, 1))
     check(got, want, what="normalize_latents layout pass")
+
+
+# ----------------------------------------------------------- conditioning (i2v) step kernels
+@pytest.mark.parametrize("lat_dtype", [torch.float32, torch.bfloat16])
+def test_guidance_step_with_conditioning_mask(lat_dtype):
+    """denoising_step with a conditioning mask (pipeline_ltx_video.py:1309-1342): hard-conditioned
+    tokens never move, soft ones start once t <= 1 - strength."""
+    from ltxmi import ops
+    from oracle import sched
+    N, C = 1200, 128
+    npred = rnd(3, N, C, seed=80)
+    lat = torch.randn(1, N, C, generator=torch.Generator().manual_seed(81)).to(lat_dtype)
+    mask = torch.zeros(1, N)
+    mask[:, :200] = 1.0
+    mask[:, 200:400] = 0.6        # 1 - 0.6 = 0.4 < t: frozen at this step
+    mask[:, 400:600] = 0.2        # 0.8 >= t: moves
+    tsch = sched.set_timesteps(8, (1, C, 3, 20, 20))
+    t = tsch[4]
+    dt = float(t - tsch[5])
+    v = sched.guidance(npred.float(), 3, 3.0, 1.0, 0.7, True, True, True)
+    cur_t = torch.min(t.expand(1).unsqueeze(-1), 1.0 - mask)
+    truth = sched.denoising_step(tsch, lat.float(), v, cur_t, mask, t)
+    d = lat.to(DEV).clone()
+    ws = torch.zeros(8, device=DEV)
+    ops.guidance_step_(npred.to(DEV), d, dt, 3.0, 1.0, 0.7, True, True, True, ws, cond_mask=mask.to(DEV), t=float(t))
+    assert 0.4 < float(t) < 0.8, float(t)
+    assert torch.equal(d.cpu()[:, :400], lat[:, :400])                      # frozen tokens are bit-identical
+    if lat_dtype == torch.float32:
+        torch.testing.assert_close(d.cpu(), truth, rtol=2e-4, atol=2e-5)
+    else:
+        check(d, truth, what="masked guidance step, bf16 latents")
+
+
+@pytest.mark.parametrize("lat_dtype", [torch.float32, torch.bfloat16])
+def test_image_cond_noise(lat_dtype):
+    from ltxmi import ops
+    from oracle import conditioning as oc
+    N, C = 777, 128
+    g = torch.Generator().manual_seed(82)
+    lat, init, noise = [torch.randn(1, N, C, generator=g).to(lat_dtype) for _ in range(3)]
+    mask = torch.zeros(1, N)
+    mask[:, :100] = 1.0
+    mask[:, 100:300] = 0.9
+    truth = oc.add_noise_to_image_conditioning_latents(0.63, init.float(), lat.float(), 0.15, mask, noise.float())
+    d = lat.to(DEV).clone()
+    ops.image_cond_noise_(d, init.to(DEV), noise.to(DEV), mask.to(DEV), 0.15, 0.63)
+    assert torch.equal(d.cpu()[:, 100:], lat[:, 100:])
+    if lat_dtype == torch.float32:
+        torch.testing.assert_close(d.cpu(), truth, rtol=1e-6, atol=1e-6)
+    else:
+        check(d, truth, what="image cond noise bf16")

@@ -12,6 +12,8 @@ where the reference's bf16 eager path is the oracle run in bf16 -- it has the re
 rounding points and is pinned to the reference's own bf16 output by
 tests/test_oracle_golden.py::test_g5_transformer_bf16_twin.
 """
+import types
+
 import pytest
 import torch
 
@@ -352,6 +354,100 @@ def test_pipeline_config1_two_steps():
     e = rel(out, truth)
     print(f"pipeline 2 steps: rel L2 {e:.3e}")
     assert e < 1e-2
+
+
+def test_prepare_conditioning_matches_oracle():
+    """Token assembly for conditioning items (pipeline_ltx_video.py:1344-1548): first-frame image,
+    mid-video sequence (prefix latents become extra tokens) and a single later frame."""
+    import ltxmi
+    from oracle import conditioning as oc, vae_encoder as oe
+    cfg, sd = vae_case("b", with_encoder=True)
+    v = build_vae(cfg, sd)
+    pipe = ltxmi.LTXVideoPipeline(types.SimpleNamespace(config=types.SimpleNamespace(causal_temporal_positioning=True)),
+                                  None, vae=v)
+    H, W, F_ = 64, 96, 33
+    g = torch.Generator().manual_seed(30)
+    img, seq, single = [(torch.rand(1, 3, n, H, W, generator=g) * 2 - 1).to(BF) for n in (1, 17, 1)]
+    init = torch.randn(1, 128, 5, 2, 3, generator=g)
+    spec = [(img, 0, 1.0), (seq, 8, 0.9), (single, 24, 0.7)]
+    twin = torch.Generator(device=DEV).manual_seed(31)
+    want = oc.prepare_conditioning(
+        [oc.ConditioningItem(m.float(), f, s) for m, f, s in spec], init.clone(), F_, H, W,
+        encode=lambda m: oe.vae_encode(sd, cfg, m),
+        noise_fn=lambda shape: torch.randn(tuple(shape), generator=twin, device=DEV, dtype=torch.float32).cpu())
+    got = pipe.prepare_conditioning([ltxmi.ConditioningItem(m.to(DEV), f, s) for m, f, s in spec],
+                                    init.to(DEV).clone(), F_, H, W, vae_per_channel_normalize=True,
+                                    generator=torch.Generator(device=DEV).manual_seed(31), sample_posterior=False)
+    assert got[3] == want[3] == 18 and got[0].shape == want[0].shape == (1, 48, 128)
+    assert torch.equal(got[1].cpu(), want[1]) and torch.equal(got[2].cpu(), want[2])
+    e = rel(got[0], want[0])
+    print(f"prepare_conditioning latents rel L2 {e:.3e}")
+    assert e < 1.5e-2                      # bf16 encoder vs fp32 oracle encoder on the conditioned tokens
+
+
+def test_pipeline_image_to_video_two_steps():
+    """i2v loop: conditioning tokens, per-token timestep, image-conditioning noise, masked Euler step
+    (pipeline_ltx_video.py:1067-1259) against the oracle's fp32 loop on the same noise draws."""
+    import ltxmi
+    from oracle import conditioning as oc, dit, sched, vae_encoder as oe
+    heads, dh, layers, caption, T = 2, 64, 2, 128, 32
+    cfg = dict(dit.default_2b_config(), num_attention_heads=heads, attention_head_dim=dh, num_layers=layers,
+               cross_attention_dim=heads * dh, caption_channels=caption)
+    sd32 = {k: v.to(BF).float() for k, v in dit.init_state_dict(cfg, seed=7).items()}
+    vcfg, vsd = vae_case("b", with_encoder=True)
+    H, W, F_ = 64, 96, 17
+    f, h, w = 3, 2, 3
+    g = torch.Generator().manual_seed(40)
+    lat0 = torch.randn(1, f * h * w, 128, generator=g)
+    pos, neg = torch.randn(1, T, caption, generator=g).to(BF), torch.randn(1, T, caption, generator=g).to(BF)
+    pmask, nmask = torch.ones(1, T), torch.ones(1, T)
+    pmask[:, 20:] = 0
+    nmask[:, 5:] = 0
+    img, single = [(torch.rand(1, 3, 1, H, W, generator=g) * 2 - 1).to(BF) for _ in range(2)]
+    spec = [(img, 0, 1.0), (single, 8, 0.8)]
+    gs, stg, rs, skip_blocks, steps, ns = 3.0, 1.0, 0.7, [1], 2, 0.15
+
+    # ---- oracle loop (fp32), noise drawn from a twin of the device generator in the product's order
+    twin = torch.Generator(device=DEV).manual_seed(41)
+    draw = lambda shape: torch.randn(tuple(shape), generator=twin, device=DEV, dtype=torch.float32).cpu()  # noqa: E731
+    tsch = sched.set_timesteps(steps, (1, 128, f, h, w))
+    lat, pc, mask, n_extra = oc.prepare_conditioning(
+        [oc.ConditioningItem(m.float(), fr, s) for m, fr, s in spec], sched.unpatchify(lat0, f, h, w).clone(),
+        F_, H, W, encode=lambda m: oe.vae_encode(vsd, vcfg, m), noise_fn=draw)
+    frac = pc.to(torch.float32)
+    frac[:, 0] = frac[:, 0] * (1.0 / 25.0)
+    fc = dit.precompute_freqs_cis(frac, cfg, torch.float32)
+    skip = dit.create_skip_layer_mask(layers, 1, 3, 2, skip_blocks, torch.float32)
+    emb = torch.cat([neg, pos, pos]).float()
+    msk = torch.cat([nmask, pmask, pmask])
+    init = lat.clone()
+    for t in tsch:
+        lat = oc.add_noise_to_image_conditioning_latents(t, init, lat, ns, mask, draw(lat.shape))
+        cur_t = oc.per_token_timestep(t, mask, 3)
+        npred = dit.transformer3d_forward(sd32, cfg, torch.cat([lat] * 3), fc, emb, cur_t,
+                                          encoder_attention_mask=msk, latent_shape=(f, h, w),
+                                          skip_layer_mask=skip, skip_layer_strategy=dit.ATTENTION_VALUES)
+        v = sched.guidance(npred, 3, gs, stg, rs, True, True, True)
+        lat = sched.denoising_step(tsch, lat, v, cur_t[:1], mask, t)
+    assert n_extra == h * w
+    truth = sched.unpatchify(lat[:, n_extra:], f, h, w)
+
+    m = build_model(cfg, sd32)
+    pipe = ltxmi.LTXVideoPipeline(m, ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1),
+                                  vae=build_vae(vcfg, vsd))
+    out = pipe(height=H, width=W, num_frames=F_, prompt_embeds=pos.to(DEV), prompt_attention_mask=pmask.to(DEV),
+               negative_prompt_embeds=neg.to(DEV), negative_prompt_attention_mask=nmask.to(DEV),
+               num_inference_steps=steps, guidance_scale=gs, stg_scale=stg, rescaling_scale=rs,
+               skip_block_list=skip_blocks, latents=lat0.to(DEV), output_type="latent",
+               conditioning_items=[ltxmi.ConditioningItem(mm.to(DEV), fr, s) for mm, fr, s in spec],
+               image_cond_noise_scale=ns, sample_conditioning_posterior=False,
+               generator=torch.Generator(device=DEV).manual_seed(41))
+    assert out.shape == truth.shape == (1, 128, f, h, w)
+    e = rel(out, truth)
+    # the hard-conditioned first frame stays the (noised) encoder output
+    e0 = rel(out[:, :, 0], truth[:, :, 0])
+    print(f"i2v pipeline 2 steps: rel L2 {e:.3e} (first frame {e0:.3e})")
+    assert e < 2e-2 and e0 < 2e-2
 
 
 def test_ulysses_processor_world1_matches_default_processor():

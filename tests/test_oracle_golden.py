@@ -238,3 +238,54 @@ def test_g11_encoder_plan_a_strided(golden):
 
 def test_g11_encoder_plan_b_space_to_depth(golden):
     _encoder_case(golden, "b")
+
+
+def test_g12_conditioning(golden):
+    """prepare_conditioning / _get_latent_spatial_position / add_noise_to_image_conditioning_latents /
+    per-token timestep / denoising_step with a conditioning mask (pipeline_ltx_video.py:606-629,
+    1145-1150, 1309-1342, 1344-1690), run by the reference's own methods."""
+    from oracle import conditioning as oc, vae_encoder as ve
+    t, meta = golden("g12_conditioning")
+    tb, _ = golden("g11_encoder_b")
+    cfg = meta["cfg"]
+    sd = sub(tb, "sd.")
+    torch.testing.assert_close(sd["encoder.conv_out.conv.weight"], t["weights_check"], rtol=0, atol=0)
+    sd["per_channel_statistics.std-of-means"] = t["per_channel_statistics.std-of-means"]
+    sd["per_channel_statistics.mean-of-means"] = t["per_channel_statistics.mean-of-means"]
+    draws = [t[f"noise.{i}"] for i in range(meta["n_prepare_draws"])]
+    it = iter(draws)
+
+    def noise_fn(shape):
+        n = next(it)
+        assert tuple(n.shape) == tuple(shape)
+        return n
+
+    items = [oc.ConditioningItem(t["img"], 0, 1.0), oc.ConditioningItem(t["seq"], 8, 0.9),
+             oc.ConditioningItem(t["single"], 24, 0.7)]
+    lat, pc, mask, n_extra = oc.prepare_conditioning(
+        items, t["init_latents"].clone(), meta["F"], meta["H"], meta["W"],
+        encode=lambda m: ve.vae_encode(sd, cfg, m), noise_fn=noise_fn)
+    assert n_extra == meta["n_extra"] and next(it, None) is None
+    tol = dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(lat, t["latents"], **tol)
+    assert torch.equal(pc, t["pixel_coords"]) and torch.equal(mask, t["mask"])
+    lat0, pc0, mask0, n0 = oc.prepare_conditioning(None, t["init_latents"].clone(), meta["F"], meta["H"], meta["W"],
+                                                   encode=None, noise_fn=None)
+    assert mask0 is None and n0 == 0 and torch.equal(lat0, t["plain.latents"]) and torch.equal(pc0, t["plain.pixel_coords"])
+    small = oc.ConditioningItem(torch.zeros(1, 3, 1, 64, 64), 0, 1.0, media_x=32, media_y=None)
+    out, lx, ly = oc.get_latent_spatial_position(t["place.in"], small, 128, 160, True)
+    assert [lx, ly] == meta["place"] and torch.equal(out, t["place.out"])
+    # loop pieces
+    ts = t["timesteps"]
+    tt = ts[meta["step_index"]]
+    noised = oc.add_noise_to_image_conditioning_latents(tt, t["latents"], t["cur_latents"], 0.15, t["mask"],
+                                                        t["noise.cond"])
+    torch.testing.assert_close(noised, t["noised"], **TOL)
+    cur_t = oc.per_token_timestep(tt, t["mask"], 3)
+    torch.testing.assert_close(cur_t, t["per_token_timestep"], rtol=0, atol=0)
+    stepped = sched.denoising_step(ts, t["noised"], t["v"], cur_t[:1], t["mask"], tt)
+    torch.testing.assert_close(stepped, t["stepped"], **TOL)
+    # the product's fused form: tokens that move use the GLOBAL dt (see include/ltxmi.h)
+    lower = ts[meta["step_index"] + 1]
+    fused = torch.where((tt - 1e-6 < 1.0 - t["mask"]).unsqueeze(-1), t["noised"] - (tt - lower) * t["v"], t["noised"])
+    torch.testing.assert_close(fused, t["stepped"], **TOL)
