@@ -177,6 +177,10 @@ typedef struct ltxmi_conv3d_args {
      * tpad = frames replicated in front (default 2 causal / 1 otherwise), out_T = output frames. */
     int32_t stride_t, stride_hw;   /* 1 or 2                                                */
     int32_t tpad, out_T;
+    /* plain (non-causal-VAE) convolutions of LatentUpsampler (latent_upsampler.py:15-149), 0 = default:
+     * kernel_t = 1: a 3x3 nn.Conv2d applied per frame (w is [Cout, 9*Cin]); time_pad_zeros = 1:
+     * nn.Conv3d(padding=1) -- the time axis is padded with zeros instead of replicated frames. */
+    int32_t kernel_t, time_pad_zeros;
 } ltxmi_conv3d_args;
 
 int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* args, void* stream);
@@ -259,6 +263,26 @@ int ltxmi_guidance_step_masked_bf16(const void* noise_pred, int64_t n, int32_t n
 int ltxmi_image_cond_noise(void* latents, const void* init_latents, const void* noise, int32_t is_bf16,
                            const float* cond_mask, int64_t tokens, int32_t channels, float noise_scale,
                            float t, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Multi-scale bridge between pass 1 and pass 2 (LatentUpsampler, latent_upsampler.py:15-149;
+ * adain_filter_latent, pipeline_ltx_video.py:1709-1737).  Its convolutions are
+ * ltxmi_conv3d_ndhwc_bf16 with kernel_t / time_pad_zeros.
+ *   groupnorm_silu: x [samples, S, C] channels-last -> y = silu(GroupNorm(groups)(x) * gamma + beta
+ *                   (+ residual)); ResBlock.forward :30-39 and initial_norm/activation :121-123.
+ *                   samples = b (dims 3) or b*f (dims 2).  workspace: >= samples*(2C + 2*groups) floats.
+ *   pixel_shuffle2d: x [frames, H, W, 4C] with channel (p1*2 + p2)*C + c -> y [frames, 2H, 2W, C]
+ *                   (PixelShuffleND(2) :93-96 with the conv rows packed (p1 p2 c)).
+ *   adain_filter:   per (b, c) plane: out = lerp(x, (x - mean_x)/std_x * std_ref + mean_ref, factor);
+ *                   latents [planes, n], reference [planes, n_ref], fp32 (is_bf16 = 0) or bf16.
+ * ------------------------------------------------------------------------------- */
+int ltxmi_groupnorm_silu_bf16(const void* x, void* y, const void* residual, int32_t samples, int64_t S,
+                              int32_t C, int32_t groups, const void* gamma, const void* beta, float eps,
+                              float* workspace, void* stream);
+int ltxmi_pixel_shuffle2d_ndhwc_bf16(const void* x, void* y, int64_t frames, int32_t H, int32_t W, int32_t C,
+                                     void* stream);
+int ltxmi_adain_filter(const void* latents, const void* reference, void* out, int32_t is_bf16, int32_t planes,
+                       int64_t n, int64_t n_ref, float factor, void* stream);
 
 #ifdef __cplusplus
 }

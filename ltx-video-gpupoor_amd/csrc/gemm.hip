@@ -47,6 +47,7 @@ struct GemmParams {
     int cB, cT, cH, cW, cCin;      // input grid
     int oT, oH, oW;                 // output grid (== input grid unless strided / extended in time)
     int sT, sHW;                    // strides (1 or 2)
+    int tzero;                      // time padding with zeros (plain nn.Conv3d) instead of frame replication
     int tpad;            // frames replicated in front (2 causal, 1 otherwise)
     int pad_replicate;   // spatial padding mode
     // depth-to-space epilogue (EPI == EPI_D2S)
@@ -142,13 +143,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
 #pragma unroll
             for (int j = 0; j < A_INSTR; ++j) {
                 int tt = cv_t[j] + dt - p.tpad;
-                tt = tt < 0 ? 0 : (tt >= p.cT ? p.cT - 1 : tt);          // time: always replicate
+                const bool toob = (tt < 0) | (tt >= p.cT);
+                tt = tt < 0 ? 0 : (tt >= p.cT ? p.cT - 1 : tt);          // time: replicate (CausalConv3d)
                 int yy = cv_y[j] + dy - 1, xx = cv_x[j] + dx - 1;
                 const bool oob = (yy < 0) | (yy >= p.cH) | (xx < 0) | (xx >= p.cW);
                 yy = yy < 0 ? 0 : (yy >= p.cH ? p.cH - 1 : yy);
                 xx = xx < 0 ? 0 : (xx >= p.cW ? p.cW - 1 : xx);
                 const uint16_t* src = a_src[j] + ((int64_t)(tt * p.cH + yy) * p.cW + xx) * p.cCin + c0;
-                if (oob && !p.pad_replicate) src = (const uint16_t*)g_zero_page;
+                if ((oob && !p.pad_replicate) | (toob && p.tzero)) src = (const uint16_t*)g_zero_page;
                 glds16(src, sa + (wave * A_INSTR + j) * 1024);
             }
         }
@@ -753,7 +755,7 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     p.gate_ld = a->gate_ld;
     p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
     p.tiles_m = p.tiles_n = 0;
-    p.cB = p.cT = p.cH = p.cW = p.cCin = 1; p.oT = p.oH = p.oW = 1; p.sT = p.sHW = 1; p.tpad = 0; p.pad_replicate = 0; p.res = nullptr; p.res_ch = 0;
+    p.cB = p.cT = p.cH = p.cW = p.cCin = 1; p.oT = p.oH = p.oW = 1; p.sT = p.sHW = 1; p.tpad = 0; p.tzero = 0; p.pad_replicate = 0; p.res = nullptr; p.res_ch = 0;
     hipStream_t s = (hipStream_t)stream;
     const int epi = (a->epilogue == LTXMI_EPI_GATE_RESIDUAL && !a->gate_table) ? EPI_RESIDUAL : a->epilogue;
     // Tile choice: 256x256 (8 waves) when it still fills the 256 CUs, else 128x128 (4 waves,
@@ -782,9 +784,12 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
                   "ltxmi_conv3d_ndhwc_bf16: strides must be 1 or 2");
     // output grid: nn.Conv3d arithmetic on the padded input (time padded by tpad frames in front, and by
     // one replicated frame behind when not causal; space padded by 1): floor((L + pad - 3) / s) + 1
-    const int tpad_front = a->tpad > 0 ? a->tpad : (a->causal ? 2 : 1);
-    const int tpad_back = (a->tpad > 0 || a->causal) ? 0 : 1;
-    const int oT = a->out_T > 0 ? a->out_T : (a->T + tpad_front + tpad_back - 3) / sT + 1;
+    const int kt = a->kernel_t > 0 ? a->kernel_t : 3;       // 1: a 3x3 nn.Conv2d applied to every frame
+    LTXMI_REQUIRE(kt == 3 || (kt == 1 && sT == 1 && a->tpad == 0 && a->out_T == 0), LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_conv3d_ndhwc_bf16: kernel_t must be 3, or 1 without time stride/padding");
+    const int tpad_front = kt == 1 ? 0 : (a->tpad > 0 ? a->tpad : (a->causal ? 2 : 1));
+    const int tpad_back = (kt == 1 || a->tpad > 0 || a->causal) ? 0 : 1;
+    const int oT = a->out_T > 0 ? a->out_T : (a->T + tpad_front + tpad_back - kt) / sT + 1;
     const int oH = (a->H + 2 - 3) / sHW + 1, oW = (a->W + 2 - 3) / sHW + 1;
     LTXMI_REQUIRE(!(a->d2s && (sT != 1 || sHW != 1 || oT != a->T)), LTXMI_ERR_UNSUPPORTED,
                   "ltxmi_conv3d_ndhwc_bf16: depth-to-space store needs a stride-1, same-size convolution");
@@ -802,17 +807,18 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
                   LTXMI_ERR_UNSUPPORTED, "ltxmi_conv3d_ndhwc_bf16: misaligned pointer");
     GemmParams p;
     p.A = (const uint16_t*)a->x; p.lda = a->Cin;
-    p.W = (const uint16_t*)a->w; p.ldw = 27ll * a->Cin;
+    p.W = (const uint16_t*)a->w; p.ldw = 9ll * kt * a->Cin;
     p.bias = a->bias ? (const uint16_t*)a->bias : zero_page_ptr();
     p.bias_stride = a->bias ? 1 : 0;
     LTXMI_REQUIRE(p.bias, LTXMI_ERR_LAUNCH, "ltxmi_conv3d_ndhwc_bf16: cannot resolve the zero page");
     p.C = (uint16_t*)a->y; p.ldc = a->Cout;
-    p.M = (int)M; p.N = a->Cout; p.K = 27 * a->Cin;
+    p.M = (int)M; p.N = a->Cout; p.K = 9 * kt * a->Cin;
     p.R = nullptr; p.ldr = 0; p.gate_table = nullptr; p.gate_temb = nullptr; p.gate_ld = 0; p.rows_per_group = 1;
     p.tiles_m = p.tiles_n = 0;
     p.cB = a->B; p.cT = a->T; p.cH = a->H; p.cW = a->W; p.cCin = a->Cin;
     p.oT = oT; p.oH = oH; p.oW = oW; p.sT = sT; p.sHW = sHW;
-    p.tpad = a->tpad > 0 ? a->tpad : (a->causal ? 2 : 1);
+    p.tpad = tpad_front;
+    p.tzero = a->time_pad_zeros ? 1 : 0;
     p.pad_replicate = a->pad_replicate;
     p.res = a->d2s ? (const uint16_t*)a->residual : nullptr;
     p.res_ch = a->res_channels;

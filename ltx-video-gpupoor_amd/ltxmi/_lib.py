@@ -35,7 +35,8 @@ class Conv3dArgs(ctypes.Structure):
                 ("B", c_int), ("T", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("Cout", c_int),
                 ("causal", c_int), ("pad_replicate", c_int), ("d2s", c_int), ("residual", c_void_p),
                 ("res_channels", c_int), ("add", c_void_p),
-                ("stride_t", c_int), ("stride_hw", c_int), ("tpad", c_int), ("out_T", c_int)]
+                ("stride_t", c_int), ("stride_hw", c_int), ("tpad", c_int), ("out_T", c_int),
+                ("kernel_t", c_int), ("time_pad_zeros", c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/ltxmi.h one to one
@@ -67,6 +68,10 @@ SIGNATURES = {
                                                 c_void_p]),
     "ltxmi_image_cond_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_float,
                                        c_float, c_void_p]),
+    "ltxmi_groupnorm_silu_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p,
+                                          c_void_p, c_float, c_void_p, c_void_p]),
+    "ltxmi_pixel_shuffle2d_ndhwc_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "ltxmi_adain_filter": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_float, c_void_p]),
     "ltxmi_patchify_to_ndhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                              c_void_p]),
     "ltxmi_space_to_depth_skip_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -214,10 +214,11 @@ def stg_blend_(a, v, m_f32):
 
 
 def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, add=None, out=None,
-           stride=(1, 1, 1), tpad=0, out_T=0):
+           stride=(1, 1, 1), tpad=0, out_T=0, kernel_t=3, time_pad_zeros=False):
     """x [B,T,H,W,Cin] NDHWC; w_packed [Cout, 27*Cin] (tap-major; (p1p2p3, c')-major rows when d2s).
     stride = (st, s, s) with st, s in {1, 2}; tpad / out_T: front time padding and output frames
-    when they differ from CausalConv3d's (0 = default), see include/ltxmi.h."""
+    when they differ from CausalConv3d's (0 = default); kernel_t = 1: per-frame 3x3 Conv2d
+    (w_packed [Cout, 9*Cin]); time_pad_zeros: nn.Conv3d zero padding in time.  See include/ltxmi.h."""
     _chk_bf16(x, w_packed, bias, residual, add, out)
     B, T, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
@@ -229,6 +230,10 @@ def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, a
     front = tpad if tpad > 0 else (2 if causal else 1)
     back = 0 if (tpad > 0 or causal) else 1
     oT = out_T if out_T > 0 else (T + front + back - 3) // st + 1
+    if kernel_t == 1:
+        oT = T
+    if w_packed.shape[1] != 9 * kernel_t * Cin:
+        raise ValueError(f"ltxmi.conv3d: packed weight has K={w_packed.shape[1]}, expected {9 * kernel_t * Cin}")
     oH, oW = (H - 1) // sh + 1, (W - 1) // sh + 1
     if out is None:
         if d2s:
@@ -240,6 +245,7 @@ def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, a
     a.B, a.T, a.H, a.W, a.Cin, a.Cout = B, T, H, W, Cin, Cout
     a.causal, a.pad_replicate, a.d2s = int(causal), int(pad_replicate), int(d2s)
     a.stride_t, a.stride_hw, a.tpad, a.out_T = st, sh, tpad, out_T
+    a.kernel_t, a.time_pad_zeros = kernel_t, int(time_pad_zeros)
     if residual is not None:
         a.residual, a.res_channels = residual.data_ptr(), residual.shape[-1]
     if add is not None:
@@ -367,3 +373,46 @@ def image_cond_noise_(latents, init_latents, noise, cond_mask, noise_scale, t):
     check(lib.ltxmi_image_cond_noise(_ptr(latents), _ptr(init_latents), _ptr(noise), int(is_bf16), _ptr(cond_mask),
                                      tokens, C, float(noise_scale), float(t), _stream()), "ltxmi_image_cond_noise")
     return latents
+
+
+def groupnorm_silu(x, gamma, beta, groups, eps, residual=None, samples=None, out=None):
+    """x channels-last [..., C]; statistics per sample over everything but the leading ``samples``
+    rows-groups (samples = B for 5-D NDHWC input by default; pass B*T for per-frame GroupNorm)."""
+    _chk_bf16(x, gamma, beta, residual, out)
+    if not x.is_contiguous() or (residual is not None and (not residual.is_contiguous() or residual.shape != x.shape)):
+        raise ValueError("ltxmi.groupnorm_silu: x / residual must be contiguous and equally shaped")
+    C = x.shape[-1]
+    samples = x.shape[0] if samples is None else samples
+    S = x.numel() // C // samples
+    out = torch.empty_like(x) if out is None else out
+    ws = torch.empty(samples * (2 * C + 2 * groups), dtype=torch.float32, device=x.device)
+    check(lib.ltxmi_groupnorm_silu_bf16(_ptr(x), _ptr(out), _ptr(residual), samples, S, C, groups, _ptr(gamma),
+                                        _ptr(beta), eps, _ptr(ws), _stream()), "ltxmi_groupnorm_silu_bf16")
+    return out
+
+
+def pixel_shuffle2d(x):
+    """x NDHWC [B,T,H,W,4C] (channel (p1 p2 c)) -> [B,T,2H,2W,C]."""
+    _chk_bf16(x)
+    B, T, H, W, C4 = x.shape
+    if not x.is_contiguous() or C4 % 32:
+        raise ValueError("ltxmi.pixel_shuffle2d: contiguous input with 4*C channels (C % 8 == 0) expected")
+    out = torch.empty((B, T, 2 * H, 2 * W, C4 // 4), dtype=BF16, device=x.device)
+    check(lib.ltxmi_pixel_shuffle2d_ndhwc_bf16(_ptr(x), _ptr(out), B * T, H, W, C4 // 4, _stream()),
+          "ltxmi_pixel_shuffle2d_ndhwc_bf16")
+    return out
+
+
+def adain_filter(latents, reference, factor=1.0):
+    """latents [B,C,...], reference [B,C,...] (NCDHW, fp32 or bf16): per-(b,c) statistics transfer."""
+    if latents.dtype != reference.dtype or latents.dtype not in (BF16, torch.float32):
+        raise TypeError("ltxmi.adain_filter: fp32 or bf16 latents and reference of the same dtype expected")
+    if latents.shape[:2] != reference.shape[:2]:
+        raise ValueError("ltxmi.adain_filter: batch/channel sizes differ")
+    latents, reference = latents.contiguous(), reference.contiguous()
+    planes = latents.shape[0] * latents.shape[1]
+    out = torch.empty_like(latents)
+    check(lib.ltxmi_adain_filter(_ptr(latents), _ptr(reference), _ptr(out), int(latents.dtype == BF16), planes,
+                                 latents.numel() // planes, reference.numel() // planes, float(factor), _stream()),
+          "ltxmi_adain_filter")
+    return out

@@ -502,7 +502,48 @@ def g12():
                                      step_index=3, n_prepare_draws=n_draws))
 
 
-CASES = {"g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
+@torch.no_grad()
+def g13():
+    """LatentUpsampler.forward (dims 3 spatial = the shipped configuration, dims 2, dims 3 spatial+temporal,
+    dims 3 temporal), adain_filter_latent and LTXMultiScalePipeline._upsample_latents."""
+    print("G13 latent upsampler")
+    ref_shims.install_pipeline_leaves()
+    import ltx_video.models.autoencoders.latent_upsampler as ref_lu
+    import ltx_video.pipelines.pipeline_ltx_video as ref_pl
+    g = torch.Generator().manual_seed(80)
+    t, meta = {}, {"cases": {}}
+    lat = torch.randn(2, 8, 3, 4, 5, generator=g)
+    t["latent"] = lat
+    cases = {"d3s": dict(dims=3, spatial_upsample=True, temporal_upsample=False),
+             "d2s": dict(dims=2, spatial_upsample=True, temporal_upsample=False),
+             "d3st": dict(dims=3, spatial_upsample=True, temporal_upsample=True),
+             "d3t": dict(dims=3, spatial_upsample=False, temporal_upsample=True)}
+    for i, (tag, kw) in enumerate(cases.items()):
+        cfg = dict(in_channels=8, mid_channels=32, num_blocks_per_stage=1, **kw)
+        torch.manual_seed(81 + i)
+        m = ref_lu.LatentUpsampler.from_config(cfg).eval()
+        for n, p in m.named_parameters():          # move the GroupNorm affine off its identity init
+            if "norm" in n:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+        for k, v in m.state_dict().items():
+            t[f"{tag}.sd.{k}"] = v
+        t[f"{tag}.out"] = m(lat)
+        meta["cases"][tag] = cfg
+        if tag == "d3s":
+            C = 8
+            std = 0.5 + torch.rand(C, generator=g)
+            mean = 0.2 * torch.randn(C, generator=g)
+            vae = types.SimpleNamespace(std_of_means=std, mean_of_means=mean)
+            ms = object.__new__(ref_pl.LTXMultiScalePipeline)
+            ms.vae = vae
+            t["per_channel_statistics.std-of-means"], t["per_channel_statistics.mean-of-means"] = std, mean
+            t["upsample_latents"] = ms._upsample_latents(m, lat)
+            t["adain"] = ref_pl.adain_filter_latent(latents=t["upsample_latents"], reference_latents=lat)
+            t["adain_half"] = ref_pl.adain_filter_latent(t["upsample_latents"], lat, factor=0.5)
+    save("g13_latent_upsampler", t, meta)
+
+
+CASES = {"g13": g13, "g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
 
 
 def main():

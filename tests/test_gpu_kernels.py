@@ -466,3 +466,76 @@ def test_image_cond_noise(lat_dtype):
         torch.testing.assert_close(d.cpu(), truth, rtol=1e-6, atol=1e-6)
     else:
         check(d, truth, what="image cond noise bf16")
+
+
+# ------------------------------------------------------------ multi-scale bridge kernels
+@pytest.mark.parametrize("kernel_t,tzero", [(3, True), (1, False)])
+@pytest.mark.parametrize("cin,cout,shape", [(64, 128, (2, 3, 5, 7)), (128, 256, (1, 2, 4, 4))])
+def test_conv3d_plain_zero_padded_and_2d(kernel_t, tzero, cin, cout, shape):
+    """nn.Conv3d(padding=1) (zero padding on all three axes) and per-frame nn.Conv2d(padding=1)
+    of LatentUpsampler (latent_upsampler.py:78-100)."""
+    import torch.nn.functional as F
+    from ltxmi import ops
+    B, T, H, W = shape
+    x = rnd(B, cin, T, H, W, seed=90)
+    b = rnd(cout, seed=92)
+    if kernel_t == 3:
+        w = rnd(cout, cin, 3, 3, 3, seed=91, scale=(27 * cin) ** -0.5)
+        truth = F.conv3d(x.float(), w.float(), b.float(), padding=1)
+        wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
+    else:
+        w = rnd(cout, cin, 3, 3, seed=91, scale=(9 * cin) ** -0.5)
+        xf = x.float().permute(0, 2, 1, 3, 4).reshape(B * T, cin, H, W)
+        truth = F.conv2d(xf, w.float(), b.float(), padding=1).view(B, T, cout, H, W).permute(0, 2, 1, 3, 4)
+        wp = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    out = ops.conv3d(ndhwc(x).to(DEV), wp.to(DEV), b.to(DEV), False, False, kernel_t=kernel_t, time_pad_zeros=tzero)
+    check(ncdhw(out.cpu()), truth, what=f"plain conv kt={kernel_t} {cin}->{cout}")
+
+
+@pytest.mark.parametrize("C,per_frame,with_res", [(64, False, False), (512, False, True), (128, True, True),
+                                                  (2048, False, False)])
+def test_groupnorm_silu(C, per_frame, with_res):
+    import torch.nn.functional as F
+    from ltxmi import ops
+    B, T, H, W = 2, 3, 5, 7
+    x = rnd(B, C, T, H, W, seed=93, scale=2) + 0.3
+    res = rnd(B, C, T, H, W, seed=94) if with_res else None
+    gamma, beta = (1 + 0.1 * rnd(C, seed=95).float()).to(BF), rnd(C, seed=96, scale=0.1)
+    xf = x.float()
+    if per_frame:
+        xf = xf.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+    gn = F.group_norm(xf, 32, gamma.float(), beta.float(), 1e-5)
+    if per_frame:
+        gn = gn.view(B, T, C, H, W).permute(0, 2, 1, 3, 4)
+    truth = F.silu(gn + (res.float() if with_res else 0))
+    out = ops.groupnorm_silu(ndhwc(x).to(DEV), gamma.to(DEV), beta.to(DEV), 32, 1e-5,
+                             residual=ndhwc(res).to(DEV) if with_res else None,
+                             samples=B * T if per_frame else B)
+    check(ncdhw(out.cpu()), truth, what=f"groupnorm+silu C={C}")
+
+
+def test_pixel_shuffle2d_is_exact():
+    from ltxmi import ops
+    from oracle import upsampler as up
+    B, T, H, W, C = 2, 3, 4, 5, 64
+    x = rnd(B * T, 4 * C, H, W, seed=97)                       # reference channel order (c p1 p2)
+    truth = up.pixel_shuffle(x, 2).view(B, T, C, 2 * H, 2 * W).permute(0, 2, 1, 3, 4)
+    xp = x.view(B * T, C, 4, H, W).transpose(1, 2).reshape(B, T, 4 * C, H, W)      # packed (p1 p2 c)
+    out = ops.pixel_shuffle2d(xp.permute(0, 1, 3, 4, 2).contiguous().to(DEV))
+    assert torch.equal(ncdhw(out.cpu()), truth)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adain_filter(dtype):
+    from ltxmi import ops
+    from oracle import upsampler as up
+    g = torch.Generator().manual_seed(98)
+    lat = (torch.randn(2, 128, 3, 8, 10, generator=g) * 1.7 + 0.4).to(dtype)
+    ref = (torch.randn(2, 128, 3, 4, 5, generator=g) * 0.6 - 0.2).to(dtype)
+    for factor in (1.0, 0.25):
+        truth = up.adain_filter_latent(lat.float(), ref.float(), factor)
+        out = ops.adain_filter(lat.to(DEV), ref.to(DEV), factor)
+        if dtype == torch.float32:
+            torch.testing.assert_close(out.cpu(), truth, rtol=1e-4, atol=1e-5)
+        else:
+            check(out, truth, what="adain bf16")

@@ -308,6 +308,40 @@ def test_vae_tiled_encode_matches_oracle_tiling():
     assert out.shape == truth.shape and rel(out, truth) < 2e-2
 
 
+@pytest.mark.parametrize("dims,mid", [(3, 64), (2, 128)])
+def test_latent_upsampler_and_bridge(dims, mid):
+    """LatentUpsampler.forward, _upsample_latents and adain_filter_latent (latent_upsampler.py:109-149,
+    pipeline_ltx_video.py:1709-1737, 1760-1772) against the oracle; spatial upsampler, dims 3 (shipped) and 2."""
+    import ltxmi
+    from oracle import upsampler as ou
+    cfg = dict(in_channels=128, mid_channels=mid, num_blocks_per_stage=2, dims=dims, spatial_upsample=True,
+               temporal_upsample=False)
+    sd = {k: v.to(BF).float() for k, v in ou.init_state_dict(cfg, seed=5).items()}
+    g = torch.Generator().manual_seed(14)
+    z = torch.randn(1, 128, 3, 6, 8, generator=g).to(BF)
+    stats = {"per_channel_statistics.std-of-means": 0.5 + torch.rand(128, generator=g),
+             "per_channel_statistics.mean-of-means": 0.2 * torch.randn(128, generator=g)}
+    truth = ou.latent_upsampler_forward(sd, cfg, z.float())
+    eager = ou.latent_upsampler_forward({k: v.to(BF) for k, v in sd.items()}, cfg, z)
+    m = ltxmi.LatentUpsampler.from_config(cfg)
+    m.load_state_dict(sd)
+    m = m.to(device=DEV, dtype=BF).eval()
+    assert m.config()["mid_channels"] == mid
+    out = m(z.to(DEV))
+    assert out.shape == truth.shape == (1, 128, 3, 12, 16)
+    e_ours, e_ref = rel(out, truth), rel(eager, truth)
+    print(f"latent upsampler dims={dims}: ours {e_ours:.3e}  reference-bf16-eager {e_ref:.3e}")
+    assert e_ours <= e_ref + RTOL, (e_ours, e_ref)
+    vae = types.SimpleNamespace(std_of_means=stats["per_channel_statistics.std-of-means"].to(DEV),
+                                mean_of_means=stats["per_channel_statistics.mean-of-means"].to(DEV))
+    want = ou.upsample_latents(sd, cfg, z.float(), stats)
+    got = ltxmi.upsample_latents(m, z.float().to(DEV), vae)
+    assert got.dtype == torch.float32 and rel(got, want) <= e_ref + 2 * RTOL
+    want = ou.adain_filter_latent(want, z.float())
+    got = ltxmi.adain_filter_latent(got, z.float().to(DEV))
+    assert rel(got, want) <= e_ref + 2 * RTOL
+
+
 # ------------------------------------------------------------------------ denoise loop
 def test_pipeline_config1_two_steps():
     """BASELINE.json configs[0]: 256x256x9, 2 denoise steps -- the plumbing case.  Device loop

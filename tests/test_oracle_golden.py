@@ -289,3 +289,19 @@ def test_g12_conditioning(golden):
     lower = ts[meta["step_index"] + 1]
     fused = torch.where((tt - 1e-6 < 1.0 - t["mask"]).unsqueeze(-1), t["noised"] - (tt - lower) * t["v"], t["noised"])
     torch.testing.assert_close(fused, t["stepped"], **TOL)
+
+
+def test_g13_latent_upsampler(golden):
+    """LatentUpsampler.forward in its four layouts, _upsample_latents and adain_filter_latent
+    (latent_upsampler.py:109-149; pipeline_ltx_video.py:1709-1737, 1760-1772)."""
+    from oracle import upsampler as up
+    t, meta = golden("g13_latent_upsampler")
+    tol = dict(rtol=1e-4, atol=2e-5)
+    for tag, cfg in meta["cases"].items():
+        out = up.latent_upsampler_forward(sub(t, f"{tag}.sd."), cfg, t["latent"])
+        assert out.shape == t[f"{tag}.out"].shape, tag
+        torch.testing.assert_close(out, t[f"{tag}.out"], **tol)
+    ul = up.upsample_latents(sub(t, "d3s.sd."), meta["cases"]["d3s"], t["latent"], t)
+    torch.testing.assert_close(ul, t["upsample_latents"], **tol)
+    torch.testing.assert_close(up.adain_filter_latent(t["upsample_latents"], t["latent"]), t["adain"], **tol)
+    torch.testing.assert_close(up.adain_filter_latent(t["upsample_latents"], t["latent"], 0.5), t["adain_half"], **tol)
