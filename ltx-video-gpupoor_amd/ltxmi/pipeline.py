@@ -182,17 +182,74 @@ class LTXVideoPipeline:
             mask = torch.cat([*extra_mask, mask], dim=1)
         return latents, pixel_coords, mask, n_extra
 
+    @staticmethod
+    def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, max_timestep=1.0,
+                           skip_initial_inference_steps=0, skip_final_inference_steps=0, **kwargs):
+        """pipeline_ltx_video.py:125-198: the scheduler's (or the given) schedule, minus skipped head/tail
+        steps, truncated to ``max_timestep``; the scheduler is re-set to exactly the returned list."""
+        if timesteps is not None:
+            scheduler.set_timesteps(timesteps=timesteps, device=device, **kwargs)
+        else:
+            scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
+        ts = list(scheduler.host_timesteps)
+        n = len(ts)
+        if (skip_initial_inference_steps < 0 or skip_final_inference_steps < 0
+                or skip_initial_inference_steps + skip_final_inference_steps >= n):
+            raise ValueError("invalid skip inference step values: must be non-negative and the sum of "
+                             "skip_initial_inference_steps and skip_final_inference_steps must be less than the "
+                             "number of inference steps")
+        ts = ts[skip_initial_inference_steps: n - skip_final_inference_steps]
+        if max_timestep < 1.0:
+            if max_timestep < min(ts):
+                raise ValueError(f"max_timestep {max_timestep} is smaller than the minimum timestep {min(ts)}")
+            ts = [t for t in ts if t <= max_timestep]
+        scheduler.set_timesteps(timesteps=ts, device=device, **kwargs)
+        return list(scheduler.host_timesteps), len(ts)
+
+    @staticmethod
+    def _guidance_tables(timesteps, guidance_scale, stg_scale, rescaling_scale, skip_block_list, guidance_timesteps):
+        """:959-1013: per-step guidance / STG / rescale / skip-block tables (lists are indexed through
+        ``guidance_timesteps``; scalars are broadcast)."""
+        n = len(timesteps)
+        mapping = None
+        if guidance_timesteps:
+            mapping = []
+            for t in timesteps:
+                idx = [i for i, v in enumerate(guidance_timesteps) if v <= t]
+                mapping.append(idx[0] if len(idx) > 0 else len(guidance_timesteps) - 1)
+
+        def table(v):
+            if not isinstance(v, list):
+                return [v] * n
+            if mapping is None:
+                raise ValueError("list-valued guidance parameters need `guidance_timesteps`")
+            return [v[mapping[i]] for i in range(n)]
+
+        gs = [x if x > 1.0 else 0.0 for x in table(guidance_scale)]
+        stg, rs = table(stg_scale), table(rescaling_scale)
+        if skip_block_list is not None:
+            if len(skip_block_list) == 0 or not isinstance(skip_block_list[0], list):
+                skip_block_list = [skip_block_list] * n
+            else:
+                skip_block_list = [skip_block_list[mapping[i]] for i in range(n)]
+        return gs, stg, rs, skip_block_list
+
     @torch.no_grad()
     def __call__(self, height: int, width: int, num_frames: int, prompt_embeds, prompt_attention_mask,
                  negative_prompt_embeds=None, negative_prompt_attention_mask=None, frame_rate: float = 25.0,
-                 num_inference_steps: int = 40, guidance_scale: float = 3.0, stg_scale: float = 1.0,
-                 rescaling_scale: float = 0.7, skip_block_list: Optional[List[int]] = None,
+                 num_inference_steps: int = 40, guidance_scale=3.0, stg_scale=1.0, rescaling_scale=0.7,
+                 skip_block_list=None,
                  skip_layer_strategy: Optional[SkipLayerStrategy] = SkipLayerStrategy.AttentionValues,
                  generator=None, latents=None, output_type: str = "latent", decode_timestep: float = 0.05,
                  decode_noise_scale: Optional[float] = 0.025, vae_per_channel_normalize: bool = True,
                  callback_on_step_end=None, latents_dtype=torch.float32,
                  conditioning_items: Optional[List[ConditioningItem]] = None, image_cond_noise_scale: float = 0.0,
-                 sample_conditioning_posterior: bool = True):
+                 sample_conditioning_posterior: bool = True, timesteps: Optional[List[float]] = None,
+                 guidance_timesteps: Optional[List[float]] = None, skip_initial_inference_steps: int = 0,
+                 skip_final_inference_steps: int = 0, strength: float = 1.0, joint_pass: bool = True):
+        """``latents``: (b, c, f, h, w) as in the reference -- re-noised to the first timestep
+        (t0 * noise + (1 - t0) * latents, :688-707) -- or, as an extension for tests, (b, N, c) patchified
+        initial noise used as is."""
         tr = self.transformer
         device = tr.device
         batch_size = prompt_embeds.shape[0]
@@ -205,18 +262,29 @@ class LTXVideoPipeline:
         C = tr.config.in_channels
         latent_shape = (batch_size, C, latent_num_frames, latent_height, latent_width)
 
-        self.scheduler.set_timesteps(num_inference_steps, samples_shape=latent_shape, device=device)   # :943-952
-        timesteps = self.scheduler.host_timesteps
+        assert strength == 1.0 or latents is not None, \
+            "strength < 1 is used for image-to-image/video-to-video - media_item or latents should be provided."
+        timesteps, num_inference_steps = self.retrieve_timesteps(                       # :943-952
+            self.scheduler, None if timesteps is not None else num_inference_steps, device, timesteps,
+            max_timestep=strength, skip_initial_inference_steps=skip_initial_inference_steps,
+            skip_final_inference_steps=skip_final_inference_steps, samples_shape=latent_shape)
 
-        guidance_scale = guidance_scale if guidance_scale > 1.0 else 0.0                # :980
-        do_cfg = guidance_scale > 1.0
-        do_stg = stg_scale > 0.0
-        do_rescale = rescaling_scale != 1.0
+        gs_tab, stg_tab, rs_tab, skip_tab = self._guidance_tables(                      # :959-1013
+            timesteps, guidance_scale, stg_scale, rescaling_scale, skip_block_list, guidance_timesteps)
+        do_cfg = any(x > 1.0 for x in gs_tab)
+        do_stg = any(x > 0.0 for x in stg_tab)
+        do_rescale = any(x != 1.0 for x in rs_tab)
         num_conds = 1 + int(do_cfg) + int(do_stg)
 
-        skip_mask = None
-        if do_stg and skip_block_list:
-            skip_mask = tr.create_skip_layer_mask(batch_size, num_conds, num_conds - 1, skip_block_list)   # :1021-1026
+        skip_masks = None
+        if do_stg and skip_tab is not None:                                              # :1016-1026
+            cache = {}
+            skip_masks = []
+            for blocks in skip_tab:
+                key = tuple(blocks)
+                if key not in cache:
+                    cache[key] = tr.create_skip_layer_mask(batch_size, num_conds, num_conds - 1, list(blocks))
+                skip_masks.append(cache[key])
 
         embeds, mask = prompt_embeds, prompt_attention_mask                              # :1035-1051
         if do_cfg:
@@ -228,10 +296,16 @@ class LTXVideoPipeline:
         embeds = embeds.to(device=device, dtype=tr.dtype)
         mask = mask.to(device)
 
-        if latents is None:
-            latents = self.prepare_latents(latent_shape, latents_dtype, device, generator)
-        else:
+        if latents is not None and latents.dim() == 3:                                   # test hook: given noise
             latents = latents.to(device=device, dtype=latents_dtype).clone()
+        else:                                                                            # prepare_latents :632-710
+            noise = self.prepare_latents(latent_shape, latents_dtype, device, generator)
+            if latents is not None:
+                assert tuple(latents.shape) == latent_shape, \
+                    f"Latents have to be of shape {latent_shape} but are {tuple(latents.shape)}."
+                given, _ = self.patchifier.patchify(latents.to(device=device, dtype=latents_dtype))
+                noise = timesteps[0] * noise + (1 - timesteps[0]) * given
+            latents = noise
 
         # conditioning items -> latents / coords / mask (+ extra tokens in front)           :1067-1085
         grid5 = self.patchifier.unpatchify(latents, latent_height, latent_width, C).contiguous()
@@ -261,12 +335,13 @@ class LTXVideoPipeline:
                 current_timestep = torch.minimum(current_timestep, one_minus_mask)
             noise_pred = tr(model_in, freqs_cis=freqs_cis, encoder_hidden_states=embeds,
                             encoder_attention_mask=mask, timestep=current_timestep,
-                            skip_layer_mask=skip_mask, skip_layer_strategy=skip_layer_strategy,
-                            latent_shape=latent_shape[2:], joint_pass=True, ltxv_model=self, return_dict=False)[0]
+                            skip_layer_mask=None if skip_masks is None else skip_masks[i],
+                            skip_layer_strategy=skip_layer_strategy,
+                            latent_shape=latent_shape[2:], joint_pass=joint_pass, ltxv_model=self, return_dict=False)[0]
             if noise_pred is None:
                 return None
             dt = self.scheduler.host_dt(t)
-            ops.guidance_step_(noise_pred, latents, dt, guidance_scale, stg_scale, rescaling_scale,
+            ops.guidance_step_(noise_pred, latents, dt, gs_tab[i], stg_tab[i], rs_tab[i],
                                do_cfg, do_stg, do_rescale, workspace, cond_mask=cond_mask, t=t)   # :1183-1241, 1309-1342
             if callback_on_step_end is not None:
                 callback_on_step_end(self, i, t, {})
@@ -283,3 +358,50 @@ class LTXVideoPipeline:
             ts = torch.tensor([decode_timestep] * latents.shape[0], device=device)
         return vae_decode(latents.to(self.vae.dtype), self.vae, True,
                           vae_per_channel_normalize=vae_per_channel_normalize, timestep=ts)
+
+
+class LTXMultiScalePipeline:
+    """pipeline_ltx_video.py:1741-1905: pass 1 at the downscaled size -> latent upsampler (x2) ->
+    AdaIN against the pass-1 latents -> pass 2 from the re-noised upsampled latents.  Prompt embeddings
+    are inputs (the T5 encoder is outside this path); the final pixel-space bilinear resize to the
+    requested size (:1893-1903) is left to the caller -- this returns pass 2's output as is."""
+
+    def __init__(self, video_pipeline: LTXVideoPipeline, latent_upsampler):
+        self.video_pipeline = video_pipeline
+        self.vae = video_pipeline.vae
+        self.latent_upsampler = latent_upsampler
+
+    def _upsample_latents(self, latent_upsampler, latents):                              # :1760-1772
+        from .latent_upsampler import upsample_latents
+        return upsample_latents(latent_upsampler, latents, self.vae)
+
+    def __call__(self, downscale_factor: float, first_pass: dict, second_pass: dict, **kwargs):
+        from .latent_upsampler import adain_filter_latent
+        vp = self.video_pipeline
+        original_output_type = kwargs.get("output_type", "latent")
+        x_width = int(kwargs["width"] * downscale_factor)                                # :1797-1800
+        downscaled_width = x_width - (x_width % vp.vae_scale_factor)
+        x_height = int(kwargs["height"] * downscale_factor)
+        downscaled_height = x_height - (x_height % vp.vae_scale_factor)
+        original_kwargs = dict(kwargs)
+
+        kw = dict(original_kwargs, output_type="latent", width=downscaled_width, height=downscaled_height,
+                  joint_pass=True)
+        kw.update(first_pass)
+        if "num_inference_steps1" in kw:
+            kw["num_inference_steps"] = kw.pop("num_inference_steps1")
+        kw.pop("num_inference_steps2", None)
+        latents = vp(**kw)
+        if latents is None:
+            return None
+
+        upsampled = self._upsample_latents(self.latent_upsampler, latents)               # :1867-1872
+        upsampled = adain_filter_latent(latents=upsampled, reference_latents=latents)
+
+        kw = dict(original_kwargs, latents=upsampled, output_type=original_output_type,
+                  width=downscaled_width * 2, height=downscaled_height * 2, joint_pass=False)
+        kw.update(second_pass)
+        if "num_inference_steps2" in kw:
+            kw["num_inference_steps"] = kw.pop("num_inference_steps2")
+        kw.pop("num_inference_steps1", None)
+        return vp(**kw)

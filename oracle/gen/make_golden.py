@@ -543,7 +543,57 @@ def g13():
     save("g13_latent_upsampler", t, meta)
 
 
-CASES = {"g13": g13, "g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
+@torch.no_grad()
+def g14():
+    """retrieve_timesteps (schedule slicing for the second pass / strength < 1) and prepare_latents
+    (given latents are re-noised to the first timestep), pipeline_ltx_video.py:125-198, 632-710."""
+    print("G14 pipeline control")
+    ref_shims.install_pipeline_leaves()
+    import ltx_video.pipelines.pipeline_ltx_video as ref_pl
+    t, meta = {}, {"cases": []}
+    shape = (1, 8, 3, 4, 6)
+
+    def sch():
+        return ref_rf.RectifiedFlowScheduler(num_train_timesteps=1000, shifting="SD3", base_resolution=None,
+                                             target_shift_terminal=0.1)
+
+    cases = [dict(num_inference_steps=10), dict(num_inference_steps=10, skip_initial_inference_steps=3),
+             dict(num_inference_steps=10, skip_final_inference_steps=4),
+             dict(num_inference_steps=30, skip_initial_inference_steps=17, skip_final_inference_steps=2),
+             dict(num_inference_steps=10, max_timestep=0.7),
+             dict(timesteps=[1.0, 0.9937, 0.9875, 0.9812, 0.975, 0.9094, 0.725, 0.4219]),
+             dict(timesteps=[0.9094, 0.725, 0.4219], skip_initial_inference_steps=1)]
+    for i, kw in enumerate(cases):
+        s = sch()
+        kw2 = dict(kw)
+        n = kw2.pop("num_inference_steps", None)
+        ts, cnt = ref_pl.retrieve_timesteps(s, n, "cpu", kw2.pop("timesteps", None), samples_shape=torch.Size(shape),
+                                            **kw2)
+        assert cnt == len(ts) and torch.equal(s.timesteps, ts)
+        t[f"ts.{i}"] = ts
+        meta["cases"].append(kw)
+    pipe = object.__new__(ref_pl.LTXVideoPipeline)
+    pipe.scheduler = sch()
+    g = torch.Generator().manual_seed(90)
+    lat = torch.randn(shape, generator=g)
+    t["latents"] = lat
+    draws = []
+
+    def logged_randn(shp, generator=None, device=None, dtype=None, layout=None):
+        n = ref_shims.randn_tensor(shp, generator=generator, device=device, dtype=dtype)
+        draws.append(n)
+        return n
+
+    ref_pl.randn_tensor = logged_randn
+    t["prepared"] = pipe.prepare_latents(lat, None, torch.tensor(0.725), shape, torch.float32, "cpu",
+                                         torch.Generator().manual_seed(91))
+    t["prepared_none"] = pipe.prepare_latents(None, None, torch.tensor(1.0), shape, torch.float32, "cpu",
+                                              torch.Generator().manual_seed(92))
+    t["noise.0"], t["noise.1"] = draws
+    save("g14_pipeline_control", t, dict(meta, shape=list(shape), t0=0.725))
+
+
+CASES = {"g14": g14, "g13": g13, "g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
 
 
 def main():

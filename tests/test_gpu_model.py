@@ -484,6 +484,79 @@ def test_pipeline_image_to_video_two_steps():
     assert e < 2e-2 and e0 < 2e-2
 
 
+def test_multiscale_pipeline_two_passes():
+    """LTXMultiScalePipeline (pipeline_ltx_video.py:1741-1905): pass 1 with per-step guidance tables at half
+    size -> LatentUpsampler -> AdaIN -> pass 2 (re-noised latents, skipped initial steps, joint_pass=False),
+    against the oracle's fp32 restatement on the same noise draws."""
+    import ltxmi
+    from oracle import dit, pipeline_ctl as pc, sched, upsampler as ou
+    heads, dh, layers, caption, T = 2, 64, 2, 128, 32
+    cfg = dict(dit.default_2b_config(), num_attention_heads=heads, attention_head_dim=dh, num_layers=layers,
+               cross_attention_dim=heads * dh, caption_channels=caption)
+    sd32 = {k: v.to(BF).float() for k, v in dit.init_state_dict(cfg, seed=7).items()}
+    ucfg = dict(in_channels=128, mid_channels=64, num_blocks_per_stage=1, dims=3, spatial_upsample=True,
+                temporal_upsample=False)
+    usd = {k: v.to(BF).float() for k, v in ou.init_state_dict(ucfg, seed=6).items()}
+    g = torch.Generator().manual_seed(50)
+    stats = {"per_channel_statistics.std-of-means": 0.5 + torch.rand(128, generator=g),
+             "per_channel_statistics.mean-of-means": 0.2 * torch.randn(128, generator=g)}
+    pos, neg = torch.randn(1, T, caption, generator=g).to(BF), torch.randn(1, T, caption, generator=g).to(BF)
+    pmask, nmask = torch.ones(1, T), torch.ones(1, T)
+    pmask[:, 20:] = 0
+    nmask[:, 5:] = 0
+    first = dict(num_inference_steps=3, guidance_scale=[1, 3], stg_scale=[0, 1], rescaling_scale=[1, 0.7],
+                 skip_block_list=[[], [1]], guidance_timesteps=[1.0, 0.95])
+    second = dict(num_inference_steps=4, skip_initial_inference_steps=2, guidance_scale=1, stg_scale=0,
+                  rescaling_scale=1, skip_block_list=None, guidance_timesteps=None)
+    f, h, w = 2, 2, 3                                             # pass-1 latent grid (64 x 96 px, 9 frames)
+
+    twin = torch.Generator(device=DEV).manual_seed(51)
+    draw = lambda shape: torch.randn(tuple(shape), generator=twin, device=DEV, dtype=torch.float32).cpu()  # noqa: E731
+
+    def oracle_pass(lat, f, h, w, ts, kw):
+        gs, stg, rs, skips, do_cfg, do_stg, do_rs = pc.guidance_tables(
+            [float(x) for x in ts], kw["guidance_scale"], kw["stg_scale"], kw["rescaling_scale"],
+            kw["skip_block_list"], kw["guidance_timesteps"])
+        nc = 1 + int(do_cfg) + int(do_stg)
+        emb = torch.cat(([neg] if do_cfg else []) + [pos] + ([pos] if do_stg else [])).float()
+        msk = torch.cat(([nmask] if do_cfg else []) + [pmask] + ([pmask] if do_stg else []))
+        fc = dit.precompute_freqs_cis(sched.fractional_coords(f, h, w, 1, 25.0), cfg, torch.float32)
+        for i, t in enumerate(ts):
+            skip = dit.create_skip_layer_mask(layers, 1, nc, nc - 1, skips[i], torch.float32) if (do_stg and skips) else None
+            npred = dit.transformer3d_forward(sd32, cfg, torch.cat([lat] * nc), fc, emb, t.expand(nc).unsqueeze(-1),
+                                              encoder_attention_mask=msk, latent_shape=(f, h, w),
+                                              skip_layer_mask=skip, skip_layer_strategy=dit.ATTENTION_VALUES)
+            v = sched.guidance(npred, nc, gs[i], stg[i], rs[i], do_cfg, do_stg, do_rs)
+            lat = sched.denoising_step(ts, lat, v, t.expand(1).unsqueeze(-1), None, t)
+        return sched.unpatchify(lat, f, h, w)
+
+    ts1 = pc.retrieve_timesteps(3, (1, 128, f, h, w))
+    lat1 = oracle_pass(draw((1, f * h * w, 128)), f, h, w, ts1, first)
+    up = ou.adain_filter_latent(ou.upsample_latents(usd, ucfg, lat1, stats), lat1)
+    shape2 = (1, 128, f, 2 * h, 2 * w)
+    ts2 = pc.retrieve_timesteps(4, shape2, skip_initial_inference_steps=2)
+    start = pc.prepare_latents(up, float(ts2[0]), draw((1, f * 4 * h * w, 128)), shape2)
+    truth = oracle_pass(sched.patchify(start)[0], f, 2 * h, 2 * w, ts2, second)
+
+    m = build_model(cfg, sd32)
+    ups = ltxmi.LatentUpsampler.from_config(ucfg)
+    ups.load_state_dict(usd)
+    ups = ups.to(device=DEV, dtype=BF).eval()
+    vae = types.SimpleNamespace(std_of_means=stats["per_channel_statistics.std-of-means"].to(DEV),
+                                mean_of_means=stats["per_channel_statistics.mean-of-means"].to(DEV))
+    vp = ltxmi.LTXVideoPipeline(m, ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1), vae=vae)
+    ms = ltxmi.LTXMultiScalePipeline(vp, ups)
+    out = ms(0.5, first, second, height=128, width=192, num_frames=9, prompt_embeds=pos.to(DEV),
+             prompt_attention_mask=pmask.to(DEV), negative_prompt_embeds=neg.to(DEV),
+             negative_prompt_attention_mask=nmask.to(DEV), output_type="latent",
+             generator=torch.Generator(device=DEV).manual_seed(51))
+    assert out.shape == truth.shape == shape2
+    torch.testing.assert_close(torch.tensor(vp.scheduler.host_timesteps), ts2, rtol=1e-6, atol=1e-7)
+    e = rel(out, truth)
+    print(f"multi-scale 2 passes: rel L2 {e:.3e}")
+    assert e < 2e-2
+
+
 def test_ulysses_processor_world1_matches_default_processor():
     """The sequence-parallel code path (UlyssesAttnProcessor + usp_dit_forward) on the GPU with a
     1-rank RCCL group: the all-to-alls are identities, so the result must equal the default

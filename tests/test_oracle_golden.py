@@ -305,3 +305,25 @@ def test_g13_latent_upsampler(golden):
     torch.testing.assert_close(ul, t["upsample_latents"], **tol)
     torch.testing.assert_close(up.adain_filter_latent(t["upsample_latents"], t["latent"]), t["adain"], **tol)
     torch.testing.assert_close(up.adain_filter_latent(t["upsample_latents"], t["latent"], 0.5), t["adain_half"], **tol)
+
+
+def test_g14_pipeline_control(golden):
+    """retrieve_timesteps and prepare_latents (pipeline_ltx_video.py:125-198, 632-710)."""
+    from oracle import pipeline_ctl as pc
+    t, meta = golden("g14_pipeline_control")
+    shape = tuple(meta["shape"])
+    for i, kw in enumerate(meta["cases"]):
+        kw = dict(kw)
+        ts = pc.retrieve_timesteps(kw.pop("num_inference_steps", None), shape, **kw)
+        torch.testing.assert_close(ts, t[f"ts.{i}"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(pc.prepare_latents(t["latents"], meta["t0"], t["noise.0"], shape), t["prepared"], **TOL)
+    torch.testing.assert_close(pc.prepare_latents(None, 1.0, t["noise.1"], shape), t["prepared_none"], **TOL)
+    # the per-step guidance tables live inside __call__ (:959-1013, cannot run on CPU): parity unpinned,
+    # checked against the reference's documented behaviour on the shipped 13B-dev settings
+    gs, stg, rs, skips, do_cfg, do_stg, do_rs = pc.guidance_tables(
+        [1.0, 0.99, 0.98, 0.93, 0.85, 0.5, 0.2], [1, 1, 6, 8, 6, 1, 1], [0, 0, 4, 4, 4, 2, 1], [1, 1, 0.5, 0.5, 1, 1, 1],
+        [[], [11, 25, 35, 39], [22, 35, 39], [28], [28], [28], [28]],
+        guidance_timesteps=[1.0, 0.996, 0.9933, 0.9850, 0.9767, 0.9008, 0.6180])
+    # first table entry whose guidance timestep is <= t: mapping = [0, 3, 4, 5, 6, 6, 6]
+    assert gs == [0.0, 8, 6, 0.0, 0.0, 0.0, 0.0] and stg == [0, 4, 4, 2, 1, 1, 1] and rs == [1, 0.5, 1, 1, 1, 1, 1]
+    assert skips == [[], [28], [28], [28], [28], [28], [28]] and do_cfg and do_stg and do_rs
