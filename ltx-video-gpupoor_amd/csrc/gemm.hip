@@ -563,16 +563,48 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     };
     // phase B of a K-tile that is not the tile's last: refill the drained stage with k-tile (+2) of the
     // stream (this tile's, or the next tile's first), fetch the next k-step-0 fragments, MFMAs on k-step 1
+    // The 8 LDS-DMA pieces of a wave are NOT issued as a burst: 64 pieces arriving at the CU's address
+    // path together (64 KB against its 64 B/clk) back-pressure every wave at its VMEM instruction, and
+    // a wave stalled there issues no MFMA (measured: the burst cost 25 % of the loop).  One piece goes
+    // out per MFMA row, so a wave waiting on its piece is covered by its SIMD partner's MFMAs.
+    auto piece = [&](int buf, const Src& t, int kt, int g) {
+        char* sa = smem + buf * STAGE_BYTES;
+        if (g < A_INSTR) glds16(t.abase + t.aoff[g] + kt * (BK * 2), sa + (wave * A_INSTR + g) * 1024);
+        else glds16(t.bbase + t.boff[g - A_INSTR] + kt * (BK * 2), sa + A_BYTES + (wave * B_INSTR + (g - A_INSTR)) * 1024);
+    };
+    static_assert(A_INSTR + B_INSTR <= MI, "one LDS-DMA piece per MFMA row");
+    auto phase_b_rows = [&](int cur, const Src& t, int kts, bool do_stage) {
+        const char* sn = smem + (cur ^ 1) * STAGE_BYTES;
+#pragma unroll
+        for (int g = 0; g < MI; ++g) {
+            if (do_stage && g < A_INSTR + B_INSTR) piece(cur, t, kts, g);
+            // next k-step-0 fragments: A rows first (two per MFMA row), then the W fragments
+            if (2 * g < MI) {
+                af0[2 * g] = *(const bf16x8*)(sn + a_off0 + (2 * g) * 2048);
+                af0[2 * g + 1] = *(const bf16x8*)(sn + a_off0 + (2 * g + 1) * 2048);
+            } else if (2 * (g - MI / 2) < NI) {
+                const int j = 2 * (g - MI / 2);
+                bf0[j] = *(const bf16x8*)(sn + b_off0 + j * 2048);
+                bf0[j + 1] = *(const bf16x8*)(sn + b_off0 + (j + 1) * 2048);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j], af1[g], acc[g][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // phase B of a K-tile that is not the tile's last: refill the drained stage with k-tile (+2) of the
+    // stream (this tile's, or the next tile's first), fetch the next k-step-0 fragments, MFMAs on k-step 1
     auto phase_b_mid = [&](int cur, int kt, int ti) {
-        if (kt + 2 < nk) {
-            stage(cur, cs, kt + 2);
-        } else if (ti + 1 < my_n) {
+        const bool same_tile = kt + 2 < nk;
+        // the last two K-tiles of a tile refill from the NEXT tile: its offsets live only for this
+        // burst (holding a second offset set across the MFMA rows does not fit the register file)
+        if (!same_tile && ti + 1 < my_n) {
             Src ns;
             set_tile(ti + 1, ns);
             stage(cur, ns, kt + 2 - nk);
         }
-        read_f0(smem + (cur ^ 1) * STAGE_BYTES);
-        mfma_f1();
+        phase_b_rows(cur, cs, kt + 2, same_tile);       // ONE copy of the MFMA rows (pieces under a scalar branch)
     };
     using first_t = std::integral_constant<bool, true>;
     using next_t = std::integral_constant<bool, false>;
