@@ -60,6 +60,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void_ptr)gsrc, (lds_void_ptr)lds_wave_base, 16, 0, 0);
 }
 
+// same through a buffer descriptor: per-lane byte offset voff (bounds-checked against the descriptor's
+// num_records: out-of-range lanes deliver zeros) + wave-uniform byte offset soff
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, uint32_t voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)lds_wave_base, 16, (int)voff, soff, 0, 0);
+}
+
 // ---- host-side error plumbing --------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);

@@ -381,36 +381,43 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
         n0 = (band * GN + rem % gn) * BN;
     };
 
-    // ---- LDS-DMA source offsets: per-lane 32-bit byte offsets from a wave-uniform tile base
+    // ---- LDS-DMA sources.  A tile's A / W panels are addressed through per-tile BUFFER DESCRIPTORS
+    // (base = the tile's first row, num_records = its valid rows), so everything that changes from tile
+    // to tile is scalar (SGPRs) and the per-lane byte offsets (row * ld + swizzled 16-byte slot) are the
+    // same for every tile; rows past M / N are out of range for the descriptor and read as zeros.
     const int srow = lane >> 3, sslot = lane & 7;
-    struct Src {
-        const char* abase; const char* bbase;
-        uint32_t aoff[A_INSTR], boff[B_INSTR];
-        int m0, n0;
-    };
-    auto set_tile = [&](int i, Src& t) {
-        tile_origin(i, t.m0, t.n0);
-        t.abase = (const char*)(p.A + (int64_t)t.m0 * p.lda);
-        t.bbase = (const char*)(p.W + (int64_t)t.n0 * p.ldw);
-        const int mlast = p.M - 1 - t.m0, nlast = p.N - 1 - t.n0;
+    uint32_t aoff[A_INSTR], boff[B_INSTR];
 #pragma unroll
-        for (int j = 0; j < A_INSTR; ++j) {
-            const int row = (wave * A_INSTR + j) * 8 + srow;
-            t.aoff[j] = (uint32_t)(min(row, mlast) * (int)p.lda * 2 + ((sslot ^ (row & 7)) << 4));
-        }
+    for (int j = 0; j < A_INSTR; ++j) {
+        const int row = (wave * A_INSTR + j) * 8 + srow;
+        aoff[j] = (uint32_t)(row * (int)p.lda * 2 + ((sslot ^ (row & 7)) << 4));
+    }
 #pragma unroll
-        for (int j = 0; j < B_INSTR; ++j) {
-            const int row = (wave * B_INSTR + j) * 8 + srow;
-            t.boff[j] = (uint32_t)(min(row, nlast) * (int)p.ldw * 2 + ((sslot ^ (row & 7)) << 4));
-        }
+    for (int j = 0; j < B_INSTR; ++j) {
+        const int row = (wave * B_INSTR + j) * 8 + srow;
+        boff[j] = (uint32_t)(row * (int)p.ldw * 2 + ((sslot ^ (row & 7)) << 4));
+    }
+    // (descriptors are kept in plain locals: the resource type cannot be a struct member in the host pass)
+    using rsrc_t = __amdgpu_buffer_rsrc_t;
+    // (the resource type can be neither a struct member, nor bound to a reference, nor captured by a
+    // lambda in the host pass: descriptors are plain locals passed BY VALUE)
+    auto rsrc_a = [&](int m0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0,
+                                                 (int)(((int64_t)(min(BM, p.M - m0) - 1) * p.lda + p.K) * 2), 0x00020000);
     };
-    auto stage = [&](int buf, const Src& t, int kt) {
+    auto rsrc_w = [&](int n0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw), 0,
+                                                 (int)(((int64_t)(min(BN, p.N - n0) - 1) * p.ldw + p.K) * 2), 0x00020000);
+    };
+    // one 1-KB piece (8 rows x 128 B) of k-tile kt: pieces 0..A_INSTR-1 are A, the rest W
+    auto piece = [&](int buf, rsrc_t ta, rsrc_t tw, int kt, int g) {
         char* sa = smem + buf * STAGE_BYTES;
-        char* sb = sa + A_BYTES;
+        if (g < A_INSTR) blds16(ta, sa + (wave * A_INSTR + g) * 1024, aoff[g], kt * (BK * 2));
+        else blds16(tw, sa + A_BYTES + (wave * B_INSTR + (g - A_INSTR)) * 1024, boff[g - A_INSTR], kt * (BK * 2));
+    };
+    auto stage = [&](int buf, rsrc_t ta, rsrc_t tw, int kt) {
 #pragma unroll
-        for (int j = 0; j < A_INSTR; ++j) glds16(t.abase + t.aoff[j] + kt * (BK * 2), sa + (wave * A_INSTR + j) * 1024);
-#pragma unroll
-        for (int j = 0; j < B_INSTR; ++j) glds16(t.bbase + t.boff[j] + kt * (BK * 2), sb + (wave * B_INSTR + j) * 1024);
+        for (int g = 0; g < A_INSTR + B_INSTR; ++g) piece(buf, ta, tw, kt, g);
     };
 
     // fragment (i) of a wave sits 16 rows = 2048 bytes below fragment (i-1) and has the same
@@ -506,10 +513,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     };
 
     const int nk = p.K / BK;                 // >= 2 on this path
-    Src cs;                                 // current tile; the next tile's offsets are rebuilt on
-    set_tile(0, cs);                        // the two occasions they are needed (registers are scarce)
-    stage(0, cs, 0);
-    stage(1, cs, 1);
+    int cs_m0, cs_n0, ns_m0 = 0, ns_n0 = 0;
+    tile_origin(0, cs_m0, cs_n0);
+    rsrc_t cs_a = rsrc_a(cs_m0), cs_w = rsrc_w(cs_n0);     // current / next tile descriptors (scalars)
+    rsrc_t ns_a = cs_a, ns_w = cs_w;
+    stage(0, cs_a, cs_w, 0);
+    stage(1, cs_a, cs_w, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
@@ -564,28 +573,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     // phase B of a K-tile that is not the tile's last: refill the drained stage with k-tile (+2) of the
     // stream (this tile's, or the next tile's first), fetch the next k-step-0 fragments, MFMAs on k-step 1
     // The 8 LDS-DMA pieces of a wave are NOT issued as a burst: 64 pieces arriving at the CU's address
-    // path together (64 KB against its 64 B/clk) back-pressure every wave at its VMEM instruction, and
-    // a wave stalled there issues no MFMA (measured: the burst cost 25 % of the loop).  One piece goes
-    // out per MFMA row, so a wave waiting on its piece is covered by its SIMD partner's MFMAs.
-    auto piece = [&](int buf, const Src& t, int kt, int g) {
-        char* sa = smem + buf * STAGE_BYTES;
-        if (g < A_INSTR) glds16(t.abase + t.aoff[g] + kt * (BK * 2), sa + (wave * A_INSTR + g) * 1024);
-        else glds16(t.bbase + t.boff[g - A_INSTR] + kt * (BK * 2), sa + A_BYTES + (wave * B_INSTR + (g - A_INSTR)) * 1024);
-    };
+    // path together back-pressure every wave at its VMEM instruction, and a wave stalled there issues
+    // no MFMA.  One piece goes out per MFMA row, so a wave waiting on its piece is covered by its SIMD
+    // partner's MFMAs.  READ_F0: also fetch the next k-step-0 fragments (not on a tile's last K-tile:
+    // they would have to live through the epilogue).
     static_assert(A_INSTR + B_INSTR <= MI, "one LDS-DMA piece per MFMA row");
-    auto phase_b_rows = [&](int cur, const Src& t, int kts, bool do_stage) {
+    auto phase_b_rows = [&](int cur, rsrc_t ta, rsrc_t tw, int kts, bool do_stage, auto f0_tag) {
+        constexpr bool READ_F0 = decltype(f0_tag)::value;
         const char* sn = smem + (cur ^ 1) * STAGE_BYTES;
 #pragma unroll
         for (int g = 0; g < MI; ++g) {
-            if (do_stage && g < A_INSTR + B_INSTR) piece(cur, t, kts, g);
-            // next k-step-0 fragments: A rows first (two per MFMA row), then the W fragments
-            if (2 * g < MI) {
-                af0[2 * g] = *(const bf16x8*)(sn + a_off0 + (2 * g) * 2048);
-                af0[2 * g + 1] = *(const bf16x8*)(sn + a_off0 + (2 * g + 1) * 2048);
-            } else if (2 * (g - MI / 2) < NI) {
-                const int j = 2 * (g - MI / 2);
-                bf0[j] = *(const bf16x8*)(sn + b_off0 + j * 2048);
-                bf0[j + 1] = *(const bf16x8*)(sn + b_off0 + (j + 1) * 2048);
+            if (g < A_INSTR + B_INSTR && do_stage) piece(cur, ta, tw, kts, g);
+            if (READ_F0) {
+                // A rows first (two per MFMA row), then the W fragments
+                if (2 * g < MI) {
+                    af0[2 * g] = *(const bf16x8*)(sn + a_off0 + (2 * g) * 2048);
+                    af0[2 * g + 1] = *(const bf16x8*)(sn + a_off0 + (2 * g + 1) * 2048);
+                } else if (2 * (g - MI / 2) < NI) {
+                    const int j = 2 * (g - MI / 2);
+                    bf0[j] = *(const bf16x8*)(sn + b_off0 + j * 2048);
+                    bf0[j + 1] = *(const bf16x8*)(sn + b_off0 + (j + 1) * 2048);
+                }
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j)
@@ -594,23 +602,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
         }
     };
     // phase B of a K-tile that is not the tile's last: refill the drained stage with k-tile (+2) of the
-    // stream (this tile's, or the next tile's first), fetch the next k-step-0 fragments, MFMAs on k-step 1
-    auto phase_b_mid = [&](int cur, int kt, int ti) {
+    // (tile, k-tile) stream -- this tile's, or the next tile's first (its descriptors are scalars) --
+    // fetch the next k-step-0 fragments, MFMAs on k-step 1.  ONE copy of the MFMA rows.
+    auto phase_b_mid = [&](int cur, int kt, bool has_next, rsrc_t ca, rsrc_t cw, rsrc_t na, rsrc_t nw) {
         const bool same_tile = kt + 2 < nk;
-        // the last two K-tiles of a tile refill from the NEXT tile: its offsets live only for this
-        // burst (holding a second offset set across the MFMA rows does not fit the register file)
-        if (!same_tile && ti + 1 < my_n) {
-            Src ns;
-            set_tile(ti + 1, ns);
-            stage(cur, ns, kt + 2 - nk);
-        }
-        phase_b_rows(cur, cs, kt + 2, same_tile);       // ONE copy of the MFMA rows (pieces under a scalar branch)
+        phase_b_rows(cur, same_tile ? ca : na, same_tile ? cw : nw, same_tile ? kt + 2 : kt + 2 - nk,
+                     same_tile || has_next, std::integral_constant<bool, true>{});
     };
     using first_t = std::integral_constant<bool, true>;
     using next_t = std::integral_constant<bool, false>;
 
     int flat = 0;                            // running k-tile count: stage parity
     for (int ti = 0; ti < my_n; ++ti) {
+        const bool has_next = ti + 1 < my_n;
+        if (has_next) {
+            tile_origin(ti + 1, ns_m0, ns_n0);
+            ns_a = rsrc_a(ns_m0);
+            ns_w = rsrc_w(ns_n0);
+        }
         // ---- K-tile 0 (never the last: nk >= 2)
         {
             const int cur = flat & 1;
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             } else {
                 sync_all();
             }
-            phase_b_mid(cur, 0, ti);
+            phase_b_mid(cur, 0, has_next, cs_a, cs_w, ns_a, ns_w);
             ++flat;
         }
         // ---- middle K-tiles
@@ -632,7 +641,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             const int cur = flat & 1;
             phase_a(smem + cur * STAGE_BYTES, next_t{});
             sync_all();
-            phase_b_mid(cur, kt, ti);
+            phase_b_mid(cur, kt, has_next, cs_a, cs_w, ns_a, ns_w);
             ++flat;
         }
         // ---- last K-tile, then the epilogue under the next tile's loads
@@ -640,19 +649,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             const int cur = flat & 1;
             phase_a(smem + cur * STAGE_BYTES, next_t{});
             sync_all();
-            mfma_f1();
-            // next tile's K-tile 1 goes into the stage this K-tile just drained; issued BEFORE the
-            // stores so that vmcnt(N_STORES) at the next barrier covers it
-            if (ti + 1 < my_n) {
-                Src ns;
-                set_tile(ti + 1, ns);
-                stage(cur, ns, 1);
-            }
+            // next tile's K-tile 1 goes into the stage this K-tile just drained, piece by piece under the
+            // MFMAs; all of it is issued BEFORE the stores, so vmcnt(N_STORES) at the next barrier covers it
+            phase_b_rows(cur, ns_a, ns_w, 1, has_next, std::integral_constant<bool, false>{});
+            epilogue(cs_m0, cs_n0);
             __builtin_amdgcn_sched_barrier(0);
-            epilogue(cs.m0, cs.n0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ti + 1 < my_n) {
-                set_tile(ti + 1, cs);
+            if (has_next) {
+                cs_a = ns_a; cs_w = ns_w; cs_m0 = ns_m0; cs_n0 = ns_n0;
                 // k-step-0 fragments of the next tile are fetched only now: holding them across the
                 // epilogue would not fit the register file next to the 128 accumulators
                 read_f0(smem + (cur ^ 1) * STAGE_BYTES);
