@@ -48,6 +48,19 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return x * fast_rcp(1.0f + fast_exp2(-2.88539008f * u));
 }
 
+// two elements at a time in packed-f32 form (v_pk_mul/fma/add_f32): same arithmetic as gelu_tanh_f with the
+// constants folded, x * 1/(1 + 2^(-x (c1 + c2 x^2))), c1 = 2 sqrt(2/pi) log2(e), c2 = 0.044715 c1
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_tanh_pk(float& a, float& b) {
+    const f32x2 x = {a, b};
+    const f32x2 u = x * x * f32x2{-0.10294324f, -0.10294324f} + f32x2{-2.30220820f, -2.30220820f};
+    const f32x2 nz = x * u;
+    const f32x2 d = f32x2{fast_exp2(nz[0]), fast_exp2(nz[1])} + f32x2{1.0f, 1.0f};
+    const f32x2 r = x * f32x2{fast_rcp(d[0]), fast_rcp(d[1])};
+    a = r[0];
+    b = r[1];
+}
+
 // ---- wave reductions -----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
