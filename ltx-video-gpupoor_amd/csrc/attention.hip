@@ -444,17 +444,30 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
         const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 #endif
         const float inv = 1.0f / l;
-        if (q_row[i] < p.Lq) {
-            uint16_t* orow = ob + (int64_t)q_row[i] * p.o_sl;
+        // A lane holds 8-byte pieces of ONE output row; stored from registers, every store instruction
+        // would touch 32 different 128-byte lines with 16 bytes each (store-issue bound, cdna guide T21).
+        // The 32 x DH block goes through a per-wave LDS scratch (the K/V stages are free now) and leaves
+        // as whole rows: 16 bytes per lane, 64 / (DH/8) complete rows per instruction.
+        char* scr = smem + wave * (32 * C::ROW_BYTES);
+        if (i == 0) __syncthreads();                      // every wave is done reading the last K/V tile
 #pragma unroll
-            for (int d = 0; d < C::DBLK; ++d)
+        for (int d = 0; d < C::DBLK; ++d)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    u32x2 w;
-                    w[0] = pack_bf16(oT[i][d][4 * g + 0] * inv, oT[i][d][4 * g + 1] * inv);
-                    w[1] = pack_bf16(oT[i][d][4 * g + 2] * inv, oT[i][d][4 * g + 3] * inv);
-                    *(u32x2*)(orow + 32 * d + 8 * g + 4 * hh) = w;
-                }
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w[0] = pack_bf16(oT[i][d][4 * g + 0] * inv, oT[i][d][4 * g + 1] * inv);
+                w[1] = pack_bf16(oT[i][d][4 * g + 2] * inv, oT[i][d][4 * g + 3] * inv);
+                const int chunk = 4 * d + g;              // 16-byte chunk of the row; this lane's half = hh
+                *(u32x2*)(scr + r * C::ROW_BYTES + ((chunk ^ (r & 7)) << 4) + hh * 8) = w;
+            }
+        constexpr int LPR = C::CHUNKS_PER_ROW;            // lanes per output row
+        constexpr int RPI = 64 / LPR;                     // rows per store instruction
+        const int q0 = qt * (4 * QW) + wave * QW + 32 * i;
+#pragma unroll
+        for (int t = 0; t < 32 / RPI; ++t) {
+            const int row = t * RPI + lane / LPR, chunk = lane % LPR;
+            const u32x4 w = *(const u32x4*)(scr + row * C::ROW_BYTES + ((chunk ^ (row & 7)) << 4));
+            if (q0 + row < p.Lq) *(u32x4*)(ob + (int64_t)(q0 + row) * p.o_sl + chunk * 8) = w;
         }
     }
 }
