@@ -175,6 +175,47 @@ __global__ __launch_bounds__(256) void pixelnorm_ada_silu_kernel(const uint16_t*
     }
 }
 
+// The same for narrow rows (C = 8 * LPR <= 256, the high-resolution end of the VAE decoder): a wave holds
+// 64 / LPR rows, LPR lanes x 16 bytes per row, so every lane carries data (the row-per-wave form above
+// leaves 3/4 of the lanes idle at C = 128 and ran at ~1 TB/s); grid-stride over row groups.
+template <int LPR>
+__global__ __launch_bounds__(256) void pixelnorm_ada_silu_narrow_kernel(const uint16_t* __restrict__ x,
+                                                                        uint16_t* __restrict__ y, int64_t rows,
+                                                                        int64_t rows_per_batch,
+                                                                        const float* __restrict__ scale,
+                                                                        const float* __restrict__ shift,
+                                                                        int apply_silu, float eps) {
+    constexpr int C = LPR * 8, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rsub = lane / LPR;
+    const int64_t stride = (int64_t)gridDim.x * (ROWS_PER_WG * RPW);
+    for (int64_t row = ((int64_t)blockIdx.x * ROWS_PER_WG + wave) * RPW + rsub; row < rows; row += stride) {
+        Chunk c = load_chunk(x + row * C + sub * 8);
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2 += c.v[e] * c.v[e];
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        const float rstd = rsqrtf(s2 * (1.0f / C) + eps);
+        float sc[8], sh[8];
+        if (scale) {
+            const int64_t bofs = (row / rows_per_batch) * C + sub * 8;
+            *(f32x4*)sc = *(const f32x4*)(scale + bofs);
+            *(f32x4*)(sc + 4) = *(const f32x4*)(scale + bofs + 4);
+            *(f32x4*)sh = *(const f32x4*)(shift + bofs);
+            *(f32x4*)(sh + 4) = *(const f32x4*)(shift + bofs + 4);
+        }
+        Chunk o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = c.v[e] * rstd;
+            if (scale) v = v * (1.0f + sc[e]) + sh[e];
+            o.v[e] = apply_silu ? silu_f(v) : v;
+        }
+        store_chunk(y + row * C + sub * 8, o);
+    }
+}
+
 // ----------------------------------------------------- channel LayerNorm with affine (norm3)
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_affine_kernel(const uint16_t* __restrict__ x,
@@ -291,6 +332,19 @@ extern "C" int ltxmi_pixelnorm_ada_silu_bf16(const void* x, void* y, int64_t row
     const int64_t grid = (rows + ROWS_PER_WG - 1) / ROWS_PER_WG;
     LTXMI_REQUIRE(grid < (1ll << 31), LTXMI_ERR_UNSUPPORTED, "ltxmi_pixelnorm_ada_silu_bf16: too many rows");
     hipStream_t s = (hipStream_t)stream;
+    if ((C == 64 || C == 128 || C == 256) && ((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0)) {
+        const int rpw = 512 / C;                                  // rows per wave
+        int64_t g = (rows + ROWS_PER_WG * rpw - 1) / (ROWS_PER_WG * rpw);
+        if (g > 256 * 16) g = 256 * 16;                           // grid-stride beyond 16 blocks per CU
+#define CALLN(LPR_)                                                                                             \
+    hipLaunchKernelGGL((pixelnorm_ada_silu_narrow_kernel<LPR_>), dim3((unsigned)g), dim3(256), 0, s,             \
+                       (const uint16_t*)x, (uint16_t*)y, rows, rows_per_batch, scale, shift, apply_silu, eps)
+        if (C == 64) CALLN(8);
+        else if (C == 128) CALLN(16);
+        else CALLN(32);
+#undef CALLN
+        return check_launch("ltxmi_pixelnorm_ada_silu_bf16");
+    }
     DISPATCH_NCH(C, hipLaunchKernelGGL((pixelnorm_ada_silu_kernel<NCH>), dim3((unsigned)grid), dim3(256), 0, s,
                                        (const uint16_t*)x, (uint16_t*)y, rows, C, rows_per_batch, scale, shift,
                                        apply_silu, eps))
