@@ -128,35 +128,36 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
         b_src[j] = p.W + (int64_t)g * p.ldw + ((sslot ^ (row & 7)) << 3);
     }
 
-    auto stage = [&](int buf, int kt) {
+    // one 1-KB LDS-DMA piece (8 rows x 128 B) of k-tile kt: pieces 0..A_INSTR-1 are A rows, the rest W rows
+    auto piece = [&](int buf, int kt, int g) {
         char* sa = smem + buf * STAGE_BYTES;
         char* sb = sa + A_BYTES;
-        if (MODE == 0) {
-#pragma unroll
-            for (int j = 0; j < A_INSTR; ++j)
-                glds16(a_src[j] + kt * BK, sa + (wave * A_INSTR + j) * 1024);
+        if (g >= A_INSTR) {
+            const int j = g - A_INSTR;
+            glds16(b_src[j] + kt * BK, sb + (wave * B_INSTR + j) * 1024);
+        } else if (MODE == 0) {
+            glds16(a_src[g] + kt * BK, sa + (wave * A_INSTR + g) * 1024);
         } else {
             // K index = tap * Cin + cin; a 64-wide K-tile never straddles taps (Cin % 64 == 0)
             const int kk = kt * BK;
             const int tap = kk / p.cCin, c0 = kk - tap * p.cCin;
             const int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-#pragma unroll
-            for (int j = 0; j < A_INSTR; ++j) {
-                int tt = cv_t[j] + dt - p.tpad;
-                const bool toob = (tt < 0) | (tt >= p.cT);
-                tt = tt < 0 ? 0 : (tt >= p.cT ? p.cT - 1 : tt);          // time: replicate (CausalConv3d)
-                int yy = cv_y[j] + dy - 1, xx = cv_x[j] + dx - 1;
-                const bool oob = (yy < 0) | (yy >= p.cH) | (xx < 0) | (xx >= p.cW);
-                yy = yy < 0 ? 0 : (yy >= p.cH ? p.cH - 1 : yy);
-                xx = xx < 0 ? 0 : (xx >= p.cW ? p.cW - 1 : xx);
-                const uint16_t* src = a_src[j] + ((int64_t)(tt * p.cH + yy) * p.cW + xx) * p.cCin + c0;
-                if ((oob && !p.pad_replicate) | (toob && p.tzero)) src = (const uint16_t*)g_zero_page;
-                glds16(src, sa + (wave * A_INSTR + j) * 1024);
-            }
+            const int j = g;
+            int tt = cv_t[j] + dt - p.tpad;
+            const bool toob = (tt < 0) | (tt >= p.cT);
+            tt = tt < 0 ? 0 : (tt >= p.cT ? p.cT - 1 : tt);          // time: replicate (CausalConv3d)
+            int yy = cv_y[j] + dy - 1, xx = cv_x[j] + dx - 1;
+            const bool oob = (yy < 0) | (yy >= p.cH) | (xx < 0) | (xx >= p.cW);
+            yy = yy < 0 ? 0 : (yy >= p.cH ? p.cH - 1 : yy);
+            xx = xx < 0 ? 0 : (xx >= p.cW ? p.cW - 1 : xx);
+            const uint16_t* src = a_src[j] + ((int64_t)(tt * p.cH + yy) * p.cW + xx) * p.cCin + c0;
+            if ((oob && !p.pad_replicate) | (toob && p.tzero)) src = (const uint16_t*)g_zero_page;
+            glds16(src, sa + (wave * A_INSTR + j) * 1024);
         }
+    };
+    auto stage = [&](int buf, int kt) {
 #pragma unroll
-        for (int j = 0; j < B_INSTR; ++j)
-            glds16(b_src[j] + kt * BK, sb + (wave * B_INSTR + j) * 1024);
+        for (int g = 0; g < A_INSTR + B_INSTR; ++g) piece(buf, kt, g);
     };
 
     // ---- fragment read offsets (bytes within a stage's A or B image), k-step 0
@@ -228,8 +229,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- phase B
-        if (kt + 2 < nk) stage(cur, kt + 2);
+        // ---- phase B.  The LDS-DMA pieces of k-tile kt+2 go out spread over the MFMA rows instead of
+        // as a burst (a wave back-pressured at its VMEM instruction issues no MFMA; with the conv gather
+        // the address arithmetic of a piece also hides under the previous row's MFMAs)
+        const bool refill = kt + 2 < nk;
         if (kt + 1 < nk) {
             const char* sn = smem + (cur ^ 1) * STAGE_BYTES;
 #pragma unroll
@@ -237,12 +240,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
 #pragma unroll
             for (int j = 0; j < NI; ++j) bf0[j] = *(const bf16x8*)(sn + b_off[j]);
         }
+        constexpr int PPR = (A_INSTR + B_INSTR + MI - 1) / MI;        // pieces per MFMA row
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
+            if (refill) {
+#pragma unroll
+                for (int q = 0; q < PPR; ++q)
+                    if (i * PPR + q < A_INSTR + B_INSTR) piece(cur, kt + 2, i * PPR + q);
+            }
 #pragma unroll
             for (int j = 0; j < NI; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j], af1[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---- epilogue.  acc[i][j][e]: row m = m0 + wm*WM + i*16 + (lane&15),

@@ -167,6 +167,32 @@ __global__ void ndhwc_to_ncdhw_kernel(const uint16_t* __restrict__ x, uint16_t* 
     }
 }
 
+// patch 4, 3 output channels (the LTX-Video decoder): one thread per input position reads its 48 channels
+// (6 x 16 B) and writes, for every (c, q), the 4 horizontally adjacent pixels r = 0..3 as one 8-byte
+// store; neighbouring threads (w, w+1) write neighbouring 8 bytes.  n = (c*4 + r)*4 + q.
+__global__ void unpatchify4_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int T, int H, int W,
+                                   int64_t total_pos) {
+    const int Wp = W * 4, Hp = H * 4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_pos; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const int h = (int)((i / W) % H);
+        const int t = (int)((i / ((int64_t)W * H)) % T);
+        const int64_t b = i / ((int64_t)W * H * T);
+        uint16_t v[48];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) *(u32x4*)(v + 8 * k) = *(const u32x4*)(x + i * 48 + 8 * k);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32x2 o;
+                o[0] = (uint32_t)v[(c * 4 + 0) * 4 + q] | ((uint32_t)v[(c * 4 + 1) * 4 + q] << 16);
+                o[1] = (uint32_t)v[(c * 4 + 2) * 4 + q] | ((uint32_t)v[(c * 4 + 3) * 4 + q] << 16);
+                *(u32x2*)(y + (((b * 3 + c) * T + t) * Hp + h * 4 + q) * (int64_t)Wp + w * 4) = o;
+            }
+    }
+}
+
 // ---------------------------------------------------------------- guidance + Euler step
 // ws[0]=sum(text*uncond) ws[1]=sum(uncond^2) ws[2]=sum(text) ws[3]=sum(text^2) ws[4]=sum(out) ws[5]=sum(out^2)
 struct GuidanceP {
@@ -331,6 +357,12 @@ extern "C" int ltxmi_unpatchify_to_ncdhw_bf16(const void* x, void* y, int32_t B,
     LTXMI_REQUIRE(x && y, LTXMI_ERR_INVALID_ARG, "ltxmi_unpatchify_to_ncdhw_bf16: NULL argument");
     LTXMI_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0 && C_out > 0 && patch > 0, LTXMI_ERR_INVALID_ARG,
                   "ltxmi_unpatchify_to_ncdhw_bf16: non-positive size");
+    if (patch == 4 && C_out == 3 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        const int64_t pos = (int64_t)B * T * H * W;
+        hipLaunchKernelGGL(unpatchify4_kernel, dim3(pw_grid(pos)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                           (const uint16_t*)x, (uint16_t*)y, T, H, W, pos);
+        return check_launch("ltxmi_unpatchify_to_ncdhw_bf16");
+    }
     const int64_t total = (int64_t)B * C_out * T * H * patch * W * patch;
     hipLaunchKernelGGL(unpatchify_kernel, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)x, (uint16_t*)y, T, H, W, C_out, patch, total);
