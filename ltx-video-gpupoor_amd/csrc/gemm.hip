@@ -527,80 +527,100 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     tile_origin(0, cs_m0, cs_n0);
     rsrc_t cs_a = rsrc_a(cs_m0), cs_w = rsrc_w(cs_n0);     // current / next tile descriptors (scalars)
     rsrc_t ns_a = cs_a, ns_w = cs_w;
+    stage(0, cs_a, cs_w, 0);
+    stage(1, cs_a, cs_w, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af0[i] = *(const bf16x8*)(smem + a_off0 + i * 2048);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bf0[j] = *(const bf16x8*)(smem + b_off0 + j * 2048);
 
-    // ---- main loop: ONE barrier per K-tile, placed where almost nothing is in flight.
-    // Between two barriers a wave issues the 64 MFMAs of K-tile kt (fragments of BOTH k-steps already in
-    // registers) and, in their shadow,
-    //   * its 8 LDS-DMA pieces of K-tile kt+2 into the stage K-tile kt occupied (free: every wave read its
-    //     fragments before the barrier), one piece per k-step-0 MFMA row -- the CU's LDS-DMA path moves
-    //     ~34 B/clk (measured with in-kernel stamps: 64 KB per K-tile ~ 1900 cycles against 2048 cycles of
-    //     MFMA), so the pieces must start streaming as early in the interval as possible and never as a
-    //     burst (a wave back-pressured at its VMEM instruction issues no MFMA);
-    //   * the fragment reads of K-tile kt+1 (landed before the barrier), each A row right behind the MFMA
-    //     row that consumed its register, the W fragments behind the last row of their k-step.
-    // Only the last few reads are outstanding when the wave reaches the barrier.  (The previous two-phase
-    // form could only issue LDS-DMA in the second half of a K-tile and lost ~20 % to it.)
-    static_assert(A_INSTR + B_INSTR <= MI, "one LDS-DMA piece per MFMA row");
-    auto read_frags = [&](const char* st) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            af0[i] = *(const bf16x8*)(st + a_off0 + i * 2048);
-            af1[i] = *(const bf16x8*)(st + a_off1 + i * 2048);
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            bf0[j] = *(const bf16x8*)(st + b_off0 + j * 2048);
-            bf1[j] = *(const bf16x8*)(st + b_off1 + j * 2048);
-        }
-    };
-    // FIRST: first K-tile of an output tile (accumulate onto 0).  READS: fetch the next K-tile's fragments
-    // (not on a tile's last K-tile: they would have to live through the epilogue).
-    auto interval = [&](int cur, rsrc_t ta, rsrc_t tw, int kts, bool do_stage, auto first_tag, auto reads_tag) {
+    constexpr int MI_HEAD = MI > 2 ? 2 : 1;
+    // phase A of one K-tile: MFMAs on the k-step-0 fragments, k-step-1 fragment reads in between.
+    // FIRST: first K-tile of an output tile, accumulate onto 0 (fresh accumulator values per tile).
+    auto phase_a = [&](const char* s, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        constexpr bool READS = decltype(reads_tag)::value;
-        const char* sn = smem + (cur ^ 1) * STAGE_BYTES;
 #pragma unroll
-        for (int g = 0; g < MI; ++g) {                      // k-step 0
-            if (g < A_INSTR + B_INSTR && do_stage) piece(cur, ta, tw, kts, g);
+        for (int i = 0; i < MI_HEAD; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    bf0[j], af0[g], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[g][j], 0, 0, 0);
-            if (READS) af0[g] = *(const bf16x8*)(sn + a_off0 + g * 2048);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (READS) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    bf0[j], af0[i], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bf0[j] = *(const bf16x8*)(sn + b_off0 + j * 2048);
-        }
+        for (int i = 0; i < MI; ++i) af1[i] = *(const bf16x8*)(s + a_off1 + i * 2048);
 #pragma unroll
-        for (int g = 0; g < MI; ++g) {                      // k-step 1
+        for (int j = 0; j < NI; ++j) bf1[j] = *(const bf16x8*)(s + b_off1 + j * 2048);
+#pragma unroll
+        for (int i = MI_HEAD; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j], af1[g], acc[g][j], 0, 0, 0);
-            if (READS) af1[g] = *(const bf16x8*)(sn + a_off1 + g * 2048);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (READS) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bf1[j] = *(const bf16x8*)(sn + b_off1 + j * 2048);
-        }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    bf0[j], af0[i], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
-    // end of an interval: this wave's LDS-DMA has landed and its fragment reads are done (__syncthreads
-    // waits lgkmcnt), then everybody's
+    auto read_f0 = [&](const char* sn) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af0[i] = *(const bf16x8*)(sn + a_off0 + i * 2048);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf0[j] = *(const bf16x8*)(sn + b_off0 + j * 2048);
+    };
+    auto mfma_f1 = [&]() {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j], af1[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // barrier between the phases: the LDS-DMA of the NEXT k-tile must have landed
     auto sync_all = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
     };
-    using yes_t = std::integral_constant<bool, true>;
-    using no_t = std::integral_constant<bool, false>;
-
-    stage(0, cs_a, cs_w, 0);
-    stage(1, cs_a, cs_w, 1);
-    sync_all();
-    read_frags(smem);
-    sync_all();                              // nobody refills stage 0 before every wave holds its fragments
+    // phase B of a K-tile that is not the tile's last: refill the drained stage with k-tile (+2) of the
+    // stream (this tile's, or the next tile's first), fetch the next k-step-0 fragments, MFMAs on k-step 1
+    // The 8 LDS-DMA pieces of a wave are NOT issued as a burst: 64 pieces arriving at the CU's address
+    // path together back-pressure every wave at its VMEM instruction, and a wave stalled there issues
+    // no MFMA.  One piece goes out per MFMA row, so a wave waiting on its piece is covered by its SIMD
+    // partner's MFMAs.  READ_F0: also fetch the next k-step-0 fragments (not on a tile's last K-tile:
+    // they would have to live through the epilogue).
+    static_assert(A_INSTR + B_INSTR <= MI, "one LDS-DMA piece per MFMA row");
+    auto phase_b_rows = [&](int cur, rsrc_t ta, rsrc_t tw, int kts, bool do_stage, auto f0_tag) {
+        constexpr bool READ_F0 = decltype(f0_tag)::value;
+        const char* sn = smem + (cur ^ 1) * STAGE_BYTES;
+#pragma unroll
+        for (int g = 0; g < MI; ++g) {
+            if (g < A_INSTR + B_INSTR && do_stage) piece(cur, ta, tw, kts, g);
+            if (READ_F0) {
+                // A rows first (two per MFMA row), then the W fragments
+                if (2 * g < MI) {
+                    af0[2 * g] = *(const bf16x8*)(sn + a_off0 + (2 * g) * 2048);
+                    af0[2 * g + 1] = *(const bf16x8*)(sn + a_off0 + (2 * g + 1) * 2048);
+                } else if (2 * (g - MI / 2) < NI) {
+                    const int j = 2 * (g - MI / 2);
+                    bf0[j] = *(const bf16x8*)(sn + b_off0 + j * 2048);
+                    bf0[j + 1] = *(const bf16x8*)(sn + b_off0 + (j + 1) * 2048);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[j], af1[g], acc[g][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // phase B of a K-tile that is not the tile's last: refill the drained stage with k-tile (+2) of the
+    // (tile, k-tile) stream -- this tile's, or the next tile's first (its descriptors are scalars) --
+    // fetch the next k-step-0 fragments, MFMAs on k-step 1.  ONE copy of the MFMA rows.
+    auto phase_b_mid = [&](int cur, int kt, bool has_next, rsrc_t ca, rsrc_t cw, rsrc_t na, rsrc_t nw) {
+        const bool same_tile = kt + 2 < nk;
+        phase_b_rows(cur, same_tile ? ca : na, same_tile ? cw : nw, same_tile ? kt + 2 : kt + 2 - nk,
+                     same_tile || has_next, std::integral_constant<bool, true>{});
+    };
+    using first_t = std::integral_constant<bool, true>;
+    using next_t = std::integral_constant<bool, false>;
 
     int flat = 0;                            // running k-tile count: stage parity
     for (int ti = 0; ti < my_n; ++ti) {
@@ -612,38 +632,43 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
         }
         // ---- K-tile 0 (never the last: nk >= 2)
         {
-            const bool same = 2 < nk;
-            interval(flat & 1, same ? cs_a : ns_a, same ? cs_w : ns_w, same ? 2 : 2 - nk, same || has_next,
-                     yes_t{}, yes_t{});
-            sync_all();
+            const int cur = flat & 1;
+            phase_a(smem + cur * STAGE_BYTES, first_t{});
+            // right after an epilogue the N_STORES younger buffer stores may still be in flight:
+            // wait for everything older than them (the LDS-DMA) only
+            if (ti > 0) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                sync_all();
+            }
+            phase_b_mid(cur, 0, has_next, cs_a, cs_w, ns_a, ns_w);
             ++flat;
         }
         // ---- middle K-tiles
         for (int kt = 1; kt < nk - 1; ++kt) {
-            const bool same = kt + 2 < nk;
-            interval(flat & 1, same ? cs_a : ns_a, same ? cs_w : ns_w, same ? kt + 2 : kt + 2 - nk,
-                     same || has_next, no_t{}, yes_t{});
+            const int cur = flat & 1;
+            phase_a(smem + cur * STAGE_BYTES, next_t{});
             sync_all();
+            phase_b_mid(cur, kt, has_next, cs_a, cs_w, ns_a, ns_w);
             ++flat;
         }
-        // ---- last K-tile (the next tile's K-tile 1 goes into its stage), then the epilogue under those loads
+        // ---- last K-tile, then the epilogue under the next tile's loads
         {
             const int cur = flat & 1;
-            interval(cur, ns_a, ns_w, 1, has_next, no_t{}, no_t{});
+            phase_a(smem + cur * STAGE_BYTES, next_t{});
+            sync_all();
+            // next tile's K-tile 1 goes into the stage this K-tile just drained, piece by piece under the
+            // MFMAs; all of it is issued BEFORE the stores, so vmcnt(N_STORES) at the next barrier covers it
+            phase_b_rows(cur, ns_a, ns_w, 1, has_next, std::integral_constant<bool, false>{});
             epilogue(cs_m0, cs_n0);
             __builtin_amdgcn_sched_barrier(0);
             if (has_next) {
                 cs_a = ns_a; cs_w = ns_w; cs_m0 = ns_m0; cs_n0 = ns_n0;
-                // the N_STORES buffer stores are the youngest vector-memory operations: wait for everything
-                // older (the LDS-DMA of the next tile's first two K-tiles) only
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_STORES) : "memory");
-                __syncthreads();
-                __builtin_amdgcn_sched_barrier(0);
-                // the next tile's first fragments are fetched only now: holding them across the epilogue
-                // would not fit the register file next to the 128 accumulators
-                read_frags(smem + (cur ^ 1) * STAGE_BYTES);
-                __syncthreads();             // (waits lgkmcnt) every wave holds its fragments: stage may be refilled
-                __builtin_amdgcn_sched_barrier(0);
+                // k-step-0 fragments of the next tile are fetched only now: holding them across the
+                // epilogue would not fit the register file next to the 128 accumulators
+                read_f0(smem + (cur ^ 1) * STAGE_BYTES);
             }
             ++flat;
         }
