@@ -27,7 +27,16 @@ def _key_bias_from_mask(attention_mask, B, Lk):
             raise NotImplementedError(
                 "pay_attention: only key biases broadcast over queries and heads are supported "
                 f"(mask dim {d} has size {m.shape[d]} with stride {m.stride(d)})")
-    return m[:, 0, 0, :].to(torch.float32).contiguous()
+    # every block of a forward passes the same mask: keep its fp32 form (one conversion kernel per
+    # forward instead of one per layer); keyed on storage + version so an in-place edit invalidates it
+    key = (m.data_ptr(), tuple(m.shape), tuple(m.stride()), m.dtype, m._version)
+    global _BIAS_CACHE
+    if _BIAS_CACHE is None or _BIAS_CACHE[0] != key:
+        _BIAS_CACHE = (key, m[:, 0, 0, :].to(torch.float32).contiguous(), m)     # m kept alive: no pointer reuse
+    return _BIAS_CACHE[1]
+
+
+_BIAS_CACHE = None
 
 
 @torch.compiler.disable()
