@@ -91,9 +91,24 @@ class StepRunner:
             _interrupt = False
         self.holder = Holder()
 
+    def enable_ulysses(self):
+        """One video over all ranks: tokens sharded, all-to-all inside self-attention (ltxmi.distributed)."""
+        from ltxmi import distributed as sp
+        sp.enable_sequence_parallel(self.m)
+        self.sp = sp
+
     @torch.no_grad()
     def step(self):
         x = self.latents.to(torch.bfloat16).expand(NUM_CONDS, -1, -1)
+        if getattr(self, "sp", None) is not None:
+            noise_pred = self.sp.usp_dit_forward(
+                self.m, x, self.freqs, encoder_hidden_states=self.embeds, encoder_attention_mask=self.mask,
+                timestep=self.t_dev, skip_layer_mask=self.skip,
+                skip_layer_strategy=self.ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=GRID,
+                ltxv_model=self.holder)[0]
+            self.ops.guidance_step_(noise_pred.contiguous(), self.latents, self.dt, 3.0, 1.0, 0.7, True, True, True,
+                                    self.ws)
+            return
         noise_pred = self.m(x, freqs_cis=self.freqs, encoder_hidden_states=self.embeds,
                             encoder_attention_mask=self.mask, timestep=self.t_dev, skip_layer_mask=self.skip,
                             skip_layer_strategy=self.ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=GRID,
@@ -186,6 +201,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-extras", action="store_true", help="skip attention-stress / VAE / CPU legs")
+    ap.add_argument("--parallelism", choices=["replicas", "ulysses"], default="replicas",
+                    help="replicas (default): every rank denoises its own video, no data-path collective, weak scaling; "
+                         "ulysses: ONE video, tokens sharded over the ranks, all-to-all inside self-attention "
+                         "(ltxmi.distributed), strong scaling")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -196,15 +215,24 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    ulysses = args.parallelism == "ulysses"
+    if world > 1 or ulysses:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     from ltxmi import ops
     runner = StepRunner(device)
-    M = NUM_CONDS * N_TOK
+    if ulysses:
+        runner.enable_ulysses()
+    sp = world if ulysses else 1                              # token (and, inside attention, head) shards
+    M = NUM_CONDS * N_TOK // sp
     key_ff1 = ("gemm", M, FF, D, ops.EPI_GELU_TANH)
-    key_attn = ("attention", NUM_CONDS, H, N_TOK, N_TOK, DH)
+    key_attn = ("attention", NUM_CONDS, H // sp, N_TOK, N_TOK, DH)
 
     for _ in range(args.warmup):
         runner.step()
@@ -228,7 +256,7 @@ def main():
 
     assert torch.isfinite(runner.latents).all(), "non-finite latents after the timed steps"
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps / elapsed
+    value = (1 if ulysses else world) * args.steps / elapsed
 
     if rank == 0:
         ff1 = times.get(key_ff1, [])
@@ -244,19 +272,19 @@ def main():
                 traffic = None
         at = times.get(key_attn, [])
         at_ms = sum(at) / max(len(at), 1)
-        at_tf = 4.0 * NUM_CONDS * N_TOK * N_TOK * D / (at_ms * 1e-3) / 1e12 if at_ms > 0 else 0.0
+        at_tf = 4.0 * NUM_CONDS * N_TOK * N_TOK * (D // sp) / (at_ms * 1e-3) / 1e12 if at_ms > 0 else 0.0
         line = {
             "metric": "denoise-steps/sec + VAE-decode frames/sec, LTX-Video 768x512x97f at 1/8 GPU",
             "value": round(value, 4), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong" if ulysses else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "LTX-Video 2B t2v 768x512x97, one denoise step = Transformer3DModel.forward "
                                    "(28 layers, D 2048, 32x64 heads, N 4992 tokens, T 256) at B_eff 3 "
                                    "(CFG + STG rows) + fused guidance/Euler; random-init weights",
-                       "tokens": N_TOK, "b_eff": NUM_CONDS, "layers": L, "parallelism": f"replicas x{world}",
+                       "tokens": N_TOK, "b_eff": NUM_CONDS, "layers": L, "parallelism": (f"ulysses sp{world}" if ulysses else f"replicas x{world}"),
                        "algorithmic_tflop_per_step": 66.4},
             "step_tflops": round(66.4 / (ms_per_step * 1e-3), 1),
-            "roofline": {"kernel": "gemm_bf16_nt_persistent_kernel<256,256,2,4,GELU_TANH> (ff.net.0, M=14976 N=8192 K=2048)",
+            "roofline": {"kernel": f"gemm_bf16_nt_persistent_kernel<256,256,2,4,GELU_TANH> (ff.net.0, M={M} N=8192 K=2048)",
                          "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                          "traffic": traffic, "launch_ms": round(ff1_ms, 4), "launches_timed": len(ff1),
