@@ -539,3 +539,56 @@ def test_adain_filter(dtype):
             torch.testing.assert_close(out.cpu(), truth, rtol=1e-4, atol=1e-5)
         else:
             check(out, truth, what="adain bf16")
+
+
+# ------------------------------------------------------------------ randomised shape sweeps
+def test_gemm_random_shapes_persistent_path():
+    """Seeded random (M, N, K) on the persistent 256x256 kernel (M >= 1024, >= 384 tiles): ragged last
+    M/N tiles through the per-tile buffer descriptors, odd tile counts per workgroup, every epilogue, a
+    result that must stay in bounds (guard columns/rows around the output are checked untouched)."""
+    import random
+    from ltxmi import ops
+    rng = random.Random(1234)
+    for case in range(14):
+        while True:
+            M = rng.randrange(1024, 9000)
+            N = 8 * rng.randrange(32, 800)
+            if ((M + 255) // 256) * ((N + 255) // 256) >= 384:
+                break
+        K = 64 * rng.randrange(2, 17)
+        epi = [ops.EPI_NONE, ops.EPI_GELU_TANH, ops.EPI_SILU, ops.EPI_GATE_RESIDUAL][case % 4]
+        a, w, b = rnd(M, K, seed=200 + case), rnd(N, K, seed=300 + case, scale=K ** -0.5), rnd(N, seed=400 + case)
+        pre = a.float() @ w.float().T + b.float()
+        guard = torch.full((M + 2, N + 16), 7.0, dtype=BF, device=DEV)
+        out = guard[1:M + 1, 8:N + 8]
+        if epi == ops.EPI_GATE_RESIDUAL:
+            res = rnd(M, N, seed=500 + case)
+            out.copy_(res.to(DEV))
+            ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), out=out, epilogue=epi, residual=out)
+            truth = res.float() + pre
+        else:
+            ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), out=out, epilogue=epi)
+            truth = {ops.EPI_NONE: pre, ops.EPI_GELU_TANH: torch.nn.functional.gelu(pre, approximate="tanh"),
+                     ops.EPI_SILU: torch.nn.functional.silu(pre)}[epi]
+        check(out, truth, what=f"random gemm {M}x{N}x{K} epi{epi}")
+        g = guard.clone()
+        g[1:M + 1, 8:N + 8] = 7.0
+        assert (g == 7.0).all(), f"random gemm {M}x{N}x{K}: wrote outside the output"
+
+
+def test_attention_random_shapes():
+    import random
+    from ltxmi import ops
+    rng = random.Random(99)
+    for case in range(10):
+        dh = rng.choice([64, 128])
+        B, H = rng.randrange(1, 3), rng.randrange(1, 40)
+        Lq, Lk = rng.randrange(1, 1500), rng.randrange(1, 1200)
+        q, k, v = rnd(B, Lq, H, dh, seed=600 + case), rnd(B, Lk, H, dh, seed=700 + case), rnd(B, Lk, H, dh, seed=800 + case)
+        bias = None
+        if case % 2:
+            bias = torch.zeros(B, Lk)
+            bias[:, rng.randrange(0, Lk):] = -10000.0
+            bias[:, 0] = 0.0
+        out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), key_bias=None if bias is None else bias.to(DEV))
+        check(out, attn_truth(q, k, v, bias), what=f"random attention B{B} H{H} Lq{Lq} Lk{Lk} dh{dh}")
