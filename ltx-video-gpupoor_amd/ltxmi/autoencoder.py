@@ -23,7 +23,7 @@ NDHWC layout directly, and SpaceToDepthDownsample's duplicated first frame is a 
 """
 import math
 from dataclasses import dataclass
-from typing import List, Optional, Tuple
+from typing import Optional
 
 import torch
 from torch import nn

@@ -15,7 +15,6 @@ Python float timesteps) is replaced by host-side schedule scalars computed once;
 host<->device synchronisation happens inside the loop.
 """
 import copy
-import math
 from dataclasses import dataclass
 from typing import List, Optional
 
