@@ -10,6 +10,11 @@ project (soasme/LTX-Video-GPUPoor) runs on its hot path:
     CausalVideoAutoencoder.decode        ltx_video/models/autoencoders/{vae,causal_video_autoencoder,...}.py
     RectifiedFlowScheduler               ltx_video/schedulers/rf.py
     guidance math of the denoise loop    ltx_video/pipelines/pipeline_ltx_video.py:1183-1222
+and, for the rows SURVEY.md 8f marks "next":
+    Encoder / SpaceToDepthDownsample / encode / vae_encode     oracle/vae_encoder.py   (golden G11)
+    prepare_conditioning, masked denoising_step, cond. noise   oracle/conditioning.py  (golden G12)
+    LatentUpsampler, adain_filter_latent, _upsample_latents    oracle/upsampler.py     (golden G13)
+    retrieve_timesteps, prepare_latents, guidance tables       oracle/pipeline_ctl.py  (golden G14; tables unpinned)
 
 Who may import it: ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
 leg of ``bench.py``.  The product package (``ltx-video-gpupoor_amd/ltxmi``) must
@@ -33,6 +38,10 @@ Pinning status
   as a stand-in for the absent package).  The reference's own in-repo duplicate of
   the sinusoid (``ltx_video/models/transformers/embeddings.py:10-50``) does pin
   ``get_timestep_embedding``.
+* Two more diffusers leaves were stood in for when generating G11-G14 (``oracle/gen``):
+  ``DiagonalGaussianDistribution`` (mean / clamped logvar; its ``sample()`` was replaced by the mean
+  because the reference draws unseeded noise there) and ``randn_tensor`` (= ``torch.randn``; the
+  draws are stored in the fixtures and replayed).  Same status: **parity unpinned** at that boundary.
 * The guidance math (CFG-star / STG / std-rescale) lives inside
   ``LTXVideoPipeline.__call__`` which cannot run on CPU (hard-coded
   ``.to("cuda")`` at pipeline_ltx_video.py:1041) -- it is restated line by line and
