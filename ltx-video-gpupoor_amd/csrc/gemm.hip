@@ -350,6 +350,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
 //     is the compile-time constant MI*NI: the first barrier after an epilogue waits with
 //     s_waitcnt vmcnt(MI*NI), i.e. for the older LDS-DMA only, not for the stores;
 // =====================================================================================
+#ifndef LTXMI_GEMM_DMA_WAVES
+#define LTXMI_GEMM_DMA_WAVES 4      // waves of the workgroup that issue the LDS-DMA: the older wave of each SIMD pair
+                                    // wins MFMA-issue arbitration and otherwise idles ~900 cycles at the barrier (8 = all: -0.7 %)
+#endif
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent_kernel(GemmParams p) {
     constexpr int NW = WAVES_M * WAVES_N;
@@ -396,17 +400,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     // to tile is scalar (SGPRs) and the per-lane byte offsets (row * ld + swizzled 16-byte slot) are the
     // same for every tile; rows past M / N are out of range for the descriptor and read as zeros.
     const int srow = lane >> 3, sslot = lane & 7;
-    uint32_t aoff[A_INSTR], boff[B_INSTR];
-#pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) {
-        const int row = (wave * A_INSTR + j) * 8 + srow;
-        aoff[j] = (uint32_t)(row * (int)p.lda * 2 + ((sslot ^ (row & 7)) << 4));
-    }
-#pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) {
-        const int row = (wave * B_INSTR + j) * 8 + srow;
-        boff[j] = (uint32_t)(row * (int)p.ldw * 2 + ((sslot ^ (row & 7)) << 4));
-    }
+    // Piece q of an operand is rows 8q .. 8q+7 of the tile: its per-lane offset is the offset of piece 0
+    // (row srow, 16-byte slot sslot ^ srow) plus q * 8 rows -- one VGPR per operand instead of one per piece.
+    // DMA_WAVES waves issue the pieces (PPW per operand each).
+    constexpr int DMA_WAVES = LTXMI_GEMM_DMA_WAVES;
+    constexpr int PPW_A = (BM / 8) / DMA_WAVES, PPW_B = (BN / 8) / DMA_WAVES;     // pieces per DMA wave
+    const uint32_t aoff0 = (uint32_t)(srow * (int)p.lda * 2 + ((sslot ^ srow) << 4));
+    const uint32_t boff0 = (uint32_t)(srow * (int)p.ldw * 2 + ((sslot ^ srow) << 4));
+    const int a_step = 16 * (int)p.lda, b_step = 16 * (int)p.ldw;                  // bytes per 8 rows
+    const bool dma_wave = wave < DMA_WAVES;
     // (descriptors are kept in plain locals: the resource type cannot be a struct member in the host pass)
     using rsrc_t = __amdgpu_buffer_rsrc_t;
     // (the resource type can be neither a struct member, nor bound to a reference, nor captured by a
@@ -419,15 +421,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
         return __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw), 0,
                                                  (int)(((int64_t)(min(BN, p.N - n0) - 1) * p.ldw + p.K) * 2), 0x00020000);
     };
-    // one 1-KB piece (8 rows x 128 B) of k-tile kt: pieces 0..A_INSTR-1 are A, the rest W
+    // one 1-KB piece (8 rows x 128 B) of k-tile kt: this wave's pieces 0..PPW_A-1 are A, the rest W
     auto piece = [&](int buf, rsrc_t ta, rsrc_t tw, int kt, int g) {
         char* sa = smem + buf * STAGE_BYTES;
-        if (g < A_INSTR) blds16(ta, sa + (wave * A_INSTR + g) * 1024, aoff[g], kt * (BK * 2));
-        else blds16(tw, sa + A_BYTES + (wave * B_INSTR + (g - A_INSTR)) * 1024, boff[g - A_INSTR], kt * (BK * 2));
+        if (g < PPW_A) {
+            const int q = wave * PPW_A + g;
+            blds16(ta, sa + q * 1024, aoff0 + (uint32_t)(q * a_step), kt * (BK * 2));
+        } else {
+            const int q = wave * PPW_B + (g - PPW_A);
+            blds16(tw, sa + A_BYTES + q * 1024, boff0 + (uint32_t)(q * b_step), kt * (BK * 2));
+        }
     };
     auto stage = [&](int buf, rsrc_t ta, rsrc_t tw, int kt) {
+        if (dma_wave) {
 #pragma unroll
-        for (int g = 0; g < A_INSTR + B_INSTR; ++g) piece(buf, ta, tw, kt, g);
+            for (int g = 0; g < PPW_A + PPW_B; ++g) piece(buf, ta, tw, kt, g);
+        }
     };
 
     // fragment (i) of a wave sits 16 rows = 2048 bytes below fragment (i-1) and has the same
@@ -587,13 +596,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     // no MFMA.  One piece goes out per MFMA row, so a wave waiting on its piece is covered by its SIMD
     // partner's MFMAs.  READ_F0: also fetch the next k-step-0 fragments (not on a tile's last K-tile:
     // they would have to live through the epilogue).
-    static_assert(A_INSTR + B_INSTR <= MI, "one LDS-DMA piece per MFMA row");
+    constexpr int PPR = (PPW_A + PPW_B + MI - 1) / MI;          // pieces per MFMA row (DMA waves only)
     auto phase_b_rows = [&](int cur, rsrc_t ta, rsrc_t tw, int kts, bool do_stage, auto f0_tag) {
         constexpr bool READ_F0 = decltype(f0_tag)::value;
         const char* sn = smem + (cur ^ 1) * STAGE_BYTES;
 #pragma unroll
         for (int g = 0; g < MI; ++g) {
-            if (g < A_INSTR + B_INSTR && do_stage) piece(cur, ta, tw, kts, g);
+            if (do_stage && dma_wave) {
+#pragma unroll
+                for (int q = 0; q < PPR; ++q)
+                    if (g * PPR + q < PPW_A + PPW_B) piece(cur, ta, tw, kts, g * PPR + q);
+            }
             if (READ_F0) {
                 // A rows first (two per MFMA row), then the W fragments
                 if (2 * g < MI) {
