@@ -98,7 +98,7 @@ class StepRunner:
         self.sp = sp
 
     @torch.no_grad()
-    def step(self):
+    def step(self, stg_alias_blocks=0):
         x = self.latents.to(torch.bfloat16).expand(NUM_CONDS, -1, -1)
         if getattr(self, "sp", None) is not None:
             noise_pred = self.sp.usp_dit_forward(
@@ -112,7 +112,7 @@ class StepRunner:
         noise_pred = self.m(x, freqs_cis=self.freqs, encoder_hidden_states=self.embeds,
                             encoder_attention_mask=self.mask, timestep=self.t_dev, skip_layer_mask=self.skip,
                             skip_layer_strategy=self.ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=GRID,
-                            ltxv_model=self.holder, return_dict=False)[0]
+                            ltxv_model=self.holder, return_dict=False, stg_alias_blocks=stg_alias_blocks)[0]
         self.ops.guidance_step_(noise_pred, self.latents, self.dt, 3.0, 1.0, 0.7, True, True, True, self.ws)
 
 
@@ -294,6 +294,18 @@ def main():
                                        "qk_frac_of_mfma_peak": round(at_tf / MFMA_BF16_PEAK_TFLOPS, 4)}},
         }
         if not args.no_extras and world == 1:
+            # NOT the headline number: the same step with the STG "perturbed" row taken as a copy of the text row
+            # for the 19 blocks before its first skipped block (bit-identical output, tests/test_gpu_model.py);
+            # ltxmi.LTXVideoPipeline does this by default (stg_row_dedup)
+            runner.step(stg_alias_blocks=19)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                runner.step(stg_alias_blocks=19)
+            torch.cuda.synchronize()
+            dd = (time.perf_counter() - t1) / args.steps
+            line["stg_row_dedup"] = {"denoise_steps_per_s": round(1.0 / dd, 4), "ms_per_step": round(dd * 1e3, 2),
+                                     "note": "exact common-subexpression elimination, not part of `value`"}
             del runner
             torch.cuda.empty_cache()
             line["attention"]["stress_98304"] = time_attention(device, 98304, 2)

@@ -245,10 +245,13 @@ class LTXVideoPipeline:
                  conditioning_items: Optional[List[ConditioningItem]] = None, image_cond_noise_scale: float = 0.0,
                  sample_conditioning_posterior: bool = True, timesteps: Optional[List[float]] = None,
                  guidance_timesteps: Optional[List[float]] = None, skip_initial_inference_steps: int = 0,
-                 skip_final_inference_steps: int = 0, strength: float = 1.0, joint_pass: bool = True):
+                 skip_final_inference_steps: int = 0, strength: float = 1.0, joint_pass: bool = True,
+                 stg_row_dedup: bool = True):
         """``latents``: (b, c, f, h, w) as in the reference -- re-noised to the first timestep
         (t0 * noise + (1 - t0) * latents, :688-707) -- or, as an extension for tests, (b, N, c) patchified
-        initial noise used as is."""
+        initial noise used as is.  ``stg_row_dedup``: the STG "perturbed" row has the text row's inputs, so it
+        is the text row until the step's first skipped block; those blocks run on one row less and the row is
+        filled in by a copy (bit-identical results, see Transformer3DModel.forward)."""
         tr = self.transformer
         device = tr.device
         batch_size = prompt_embeds.shape[0]
@@ -332,8 +335,12 @@ class LTXVideoPipeline:
             current_timestep = t_dev[i].expand(num_conds).unsqueeze(-1)                  # [B_eff, 1]
             if cond_mask is not None:                                                    # :1145-1150, [B_eff, N]
                 current_timestep = torch.minimum(current_timestep, one_minus_mask)
+            alias = 0
+            if stg_row_dedup and do_stg and joint_pass:
+                blocks = skip_tab[i] if skip_tab is not None else []
+                alias = min(blocks) if len(blocks) > 0 else len(tr.transformer_blocks)
             noise_pred = tr(model_in, freqs_cis=freqs_cis, encoder_hidden_states=embeds,
-                            encoder_attention_mask=mask, timestep=current_timestep,
+                            encoder_attention_mask=mask, timestep=current_timestep, stg_alias_blocks=alias,
                             skip_layer_mask=None if skip_masks is None else skip_masks[i],
                             skip_layer_strategy=skip_layer_strategy,
                             latent_shape=latent_shape[2:], joint_pass=joint_pass, ltxv_model=self, return_dict=False)[0]

@@ -196,7 +196,12 @@ class Transformer3DModel(nn.Module):
                 attention_mask: Optional[torch.Tensor] = None, encoder_attention_mask: Optional[torch.Tensor] = None,
                 skip_layer_mask: Optional[torch.Tensor] = None,
                 skip_layer_strategy: Optional[SkipLayerStrategy] = None, latent_shape=None, joint_pass=True,
-                ltxv_model=None, mixed=False, return_dict: bool = True):
+                ltxv_model=None, mixed=False, return_dict: bool = True, stg_alias_blocks: int = 0):
+        """``stg_alias_blocks`` (extension, default off): the caller guarantees that the LAST batch row has
+        exactly the inputs of the row before it (the STG "perturbed" row is the text row until its first
+        skipped block, pipeline_ltx_video.py:1035-1051) -- the first ``stg_alias_blocks`` blocks then run on
+        B - 1 rows and the last row is filled in by a copy.  Bit-identical to running all rows (every kernel
+        computes a row independently of the others, in the same order)."""
         if self.dtype != BF16:
             raise TypeError("ltxmi.Transformer3DModel runs in bfloat16 only: call .to(torch.bfloat16)")
         if mixed:
@@ -244,8 +249,25 @@ class Transformer3DModel(nn.Module):
             m._ltxmi_host = rows if sl is None else rows[sl]
             return m
 
+        first_block = 0
+        if joint_pass and stg_alias_blocks and B >= 2:
+            first_block = min(int(stg_alias_blocks), len(self.transformer_blocks))
+            keep = slice(0, B - 1)
+            hs = hidden_states[keep]                                        # a view: the blocks update it in place
+            for block_idx in range(first_block):
+                self.transformer_blocks[block_idx](
+                    hs, freqs_cis=freqs_cis, attention_mask=attention_mask,
+                    encoder_hidden_states=encoder_hidden_states[keep],
+                    encoder_attention_mask=None if encoder_attention_mask is None else encoder_attention_mask[keep],
+                    timestep=temb[keep], cross_attention_kwargs=cross_attention_kwargs, class_labels=class_labels,
+                    skip_layer_mask=layer_mask(block_idx, keep), skip_layer_strategy=skip_layer_strategy)
+                if ltxv_model is not None and ltxv_model._interrupt:
+                    return [None]
+            hidden_states[B - 1].copy_(hidden_states[B - 2])
         if joint_pass:
             for block_idx, block in enumerate(self.transformer_blocks):
+                if block_idx < first_block:
+                    continue
                 hidden_states = block(hidden_states, freqs_cis=freqs_cis, attention_mask=attention_mask,
                                       encoder_hidden_states=encoder_hidden_states,
                                       encoder_attention_mask=encoder_attention_mask, timestep=temb,

@@ -131,6 +131,29 @@ def test_transformer_joint_pass_false_matches_joint():
     assert rel(b, a) < 4e-3
 
 
+def test_transformer_stg_row_alias_is_bit_identical():
+    """stg_alias_blocks: the perturbed row computed as a copy of the text row up to the first skipped block
+    gives bit-identical output to computing all three rows."""
+    grid = (2, 4, 6)
+    cfg, sd32, x, enc, mask, ts, frac = dit_case(2, 64, 4, grid, 3, 16, seed=3)
+    x[2] = x[1]
+    enc[2] = enc[1]
+    mask[2] = mask[1]
+    ts[2] = ts[1]
+    m = build_model(cfg, sd32)
+    fc = m.precompute_freqs_cis(frac.to(DEV))
+    from ltxmi import SkipLayerStrategy
+    for strategy in (SkipLayerStrategy.AttentionValues, SkipLayerStrategy.TransformerBlock):
+        slm = m.create_skip_layer_mask(1, 3, 2, [2, 3])
+        kw = dict(freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV),
+                  timestep=ts.to(DEV), skip_layer_mask=slm, skip_layer_strategy=strategy, latent_shape=grid,
+                  return_dict=False)
+        full = m(x.to(DEV).clone(), **kw)[0]
+        dedup = m(x.to(DEV).clone(), stg_alias_blocks=2, **kw)[0]
+        assert torch.equal(full, dedup)
+        assert not torch.equal(full[1], full[2])            # the perturbation does act after block 2
+
+
 def test_transformer_interrupt_and_output_types():
     import ltxmi
     grid, B, T = (2, 2, 4), 1, 16
