@@ -81,7 +81,7 @@ class StepRunner:
         frac = sched.fractional_coords(*GRID, 1, 25.0).to(device)
         self.freqs = self.m.precompute_freqs_cis(frac)
         self.skip = self.m.create_skip_layer_mask(1, NUM_CONDS, NUM_CONDS - 1, [19])
-        self.ws = torch.zeros(8, device=device)
+        self.ws = torch.empty(ops.GUIDANCE_WORKSPACE_FLOATS, device=device)
         ts = sched.set_timesteps(40, (1, C_LAT) + GRID)
         self.t = float(ts[10])
         self.dt = float(ts[10] - ts[11])

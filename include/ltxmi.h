@@ -237,8 +237,10 @@ int ltxmi_ndhwc_to_ncdhw_bf16(const void* x, int64_t ldx, int32_t c0, void* y, i
  *   euler   : x <- x - dt * v               ltx_video/schedulers/rf.py:375
  * noise_pred: bf16 [num_conds, n] (one sample, chunk order uncond/text/perturbed as built at
  * pipeline_ltx_video.py:1035-1051); latents: [n], fp32 (latents_bf16 = 0) or bf16 (= 1).
- * workspace: >= 8 floats, zeroed by the call (stream-ordered memset).
+ * workspace: >= LTXMI_GUIDANCE_WORKSPACE_FLOATS floats (per-block partial sums: the reductions use no
+ * atomics, so the step is run-to-run deterministic); contents need not be initialised.
  * ------------------------------------------------------------------------------- */
+#define LTXMI_GUIDANCE_WORKSPACE_FLOATS 2048
 int ltxmi_guidance_step_bf16(const void* noise_pred, int64_t n, int32_t num_conds,
                              float guidance_scale, float stg_scale, float rescaling_scale,
                              int32_t do_cfg, int32_t do_stg, int32_t do_rescale,

@@ -194,7 +194,7 @@ __global__ void unpatchify4_kernel(const uint16_t* __restrict__ x, uint16_t* __r
 }
 
 // ---------------------------------------------------------------- guidance + Euler step
-// ws[0]=sum(text*uncond) ws[1]=sum(uncond^2) ws[2]=sum(text) ws[3]=sum(text^2) ws[4]=sum(out) ws[5]=sum(out^2)
+// pass 1 sums: text*uncond, uncond^2, text, text^2; pass 2 sums: out, out^2 (per-block partials in the workspace)
 struct GuidanceP {
     const uint16_t* np; int64_t n; int num_conds;
     float gs, stg, rs; int do_cfg, do_stg, do_rescale;
@@ -202,10 +202,13 @@ struct GuidanceP {
     const float* cond_mask; int channels; float t;      // conditioning: token n steps iff t - 1e-6 < 1 - cond_mask[n]
 };
 
-// block sum through LDS, then ONE float atomic per block and value (256 blocks at most: the
-// per-wave form serialised ~32k same-address atomics, 0.4 ms per call)
+// Deterministic two-level sums (no atomics: run-to-run identical latents): every block writes its partial
+// to part[block][NV]; the consumer kernel adds the partials of all blocks in block order.
+// Workspace layout (floats): [8 .. 8 + 4*256) partials of pass 1, [1032 .. 1032 + 2*256) partials of pass 2.
+constexpr int GD_MAX_BLOCKS = 256;
+constexpr int GD_PART1 = 8, GD_PART2 = 8 + 4 * GD_MAX_BLOCKS;
 template <int NV>
-__device__ __forceinline__ void block_atomic_add(float (&v)[NV], float* dst) {
+__device__ __forceinline__ void block_partial_store(float (&v)[NV], float* part) {
     __shared__ float red[NV][PW_THREADS / 64];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -217,8 +220,20 @@ __device__ __forceinline__ void block_atomic_add(float (&v)[NV], float* dst) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < PW_THREADS / 64; ++w) s += red[threadIdx.x][w];
-        atomicAdd(dst + threadIdx.x, s);
+        part[blockIdx.x * NV + threadIdx.x] = s;
     }
+}
+template <int NV>
+__device__ __forceinline__ void sum_partials(const float* part, int nblocks, float (&out)[NV]) {
+    __shared__ float tot[NV];
+    if (threadIdx.x < NV) {
+        float s = 0.f;
+        for (int b = 0; b < nblocks; ++b) s += part[b * NV + threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) out[i] = tot[i];
 }
 
 __device__ __forceinline__ void guidance_fetch(const GuidanceP& p, int64_t i, float& unc, float& txt, float& ptb) {
@@ -248,11 +263,13 @@ __global__ void guidance_reduce1(GuidanceP p) {
         a0 += t * u; a1 += u * u; a2 += t; a3 += t * t;
     }
     float acc[4] = {a0, a1, a2, a3};
-    block_atomic_add(acc, p.ws + 0);
+    block_partial_store(acc, p.ws + GD_PART1);
 }
 
 __global__ void guidance_reduce2(GuidanceP p) {
-    const float alpha = p.ws[0] / (p.ws[1] + 1e-8f);
+    float s1[4];
+    sum_partials(p.ws + GD_PART1, gridDim.x, s1);
+    const float alpha = s1[0] / (s1[1] + 1e-8f);
     float a4 = 0, a5 = 0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
         float u, t, q;
@@ -261,16 +278,19 @@ __global__ void guidance_reduce2(GuidanceP p) {
         a4 += o; a5 += o * o;
     }
     float acc[2] = {a4, a5};
-    block_atomic_add(acc, p.ws + 4);
+    block_partial_store(acc, p.ws + GD_PART2);
 }
 
 __global__ void guidance_apply(GuidanceP p) {
-    const float alpha = p.ws[0] / (p.ws[1] + 1e-8f);
+    float s1[4], s2[2];
+    sum_partials(p.ws + GD_PART1, gridDim.x, s1);
+    sum_partials(p.ws + GD_PART2, gridDim.x, s2);
+    const float alpha = s1[0] / (s1[1] + 1e-8f);
     float factor = 1.f;
     if (p.do_stg && p.do_rescale && p.stg > 0.f) {
         const float n = (float)p.n;
-        const float var_t = fmaxf((p.ws[3] - p.ws[2] * p.ws[2] / n) / (n - 1.f), 0.f);   // torch .std(): unbiased
-        const float var_o = fmaxf((p.ws[5] - p.ws[4] * p.ws[4] / n) / (n - 1.f), 0.f);
+        const float var_t = fmaxf((s1[3] - s1[2] * s1[2] / n) / (n - 1.f), 0.f);   // torch .std(): unbiased
+        const float var_o = fmaxf((s2[1] - s2[0] * s2[0] / n) / (n - 1.f), 0.f);
         factor = p.rs * (sqrtf(var_t) / sqrtf(var_o)) + (1.f - p.rs);
     }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -389,10 +409,6 @@ extern "C" int ltxmi_guidance_step_masked_bf16(const void* noise_pred, int64_t n
     p.cond_mask = cond_mask; p.channels = channels > 0 ? channels : 1; p.t = t;
     LTXMI_REQUIRE(!cond_mask || (channels > 0 && n % channels == 0), LTXMI_ERR_INVALID_ARG,
                   "ltxmi_guidance_step_bf16: n=%lld is not a multiple of channels=%d", (long long)n, channels);
-    if (hipMemsetAsync(workspace, 0, 8 * sizeof(float), s) != hipSuccess) {
-        set_error("ltxmi_guidance_step_bf16: hipMemsetAsync failed");
-        return LTXMI_ERR_LAUNCH;
-    }
     unsigned g = pw_grid(n);
     if (g > 256) g = 256;
     hipLaunchKernelGGL(guidance_reduce1, dim3(g), dim3(PW_THREADS), 0, s, p);

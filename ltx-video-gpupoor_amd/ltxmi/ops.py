@@ -331,6 +331,9 @@ def ndhwc_to_ncdhw(x, c0, C, std=None, mean=None):
     return out
 
 
+GUIDANCE_WORKSPACE_FLOATS = 2048      # include/ltxmi.h: LTXMI_GUIDANCE_WORKSPACE_FLOATS
+
+
 def guidance_step_(noise_pred, latents, dt, guidance_scale, stg_scale, rescaling_scale, do_cfg, do_stg, do_rescale,
                    workspace, cond_mask=None, t=0.0):
     """noise_pred bf16 [num_conds, N, C] (one sample); latents fp32/bf16 [1, N, C], updated in place.
@@ -343,6 +346,8 @@ def guidance_step_(noise_pred, latents, dt, guidance_scale, stg_scale, rescaling
         raise TypeError("ltxmi.guidance_step_: latents must be fp32 or bf16")
     if not latents.is_contiguous() or latents.numel() != n:
         raise ValueError("ltxmi.guidance_step_: latents must be contiguous and match one chunk of noise_pred")
+    if workspace.dtype != torch.float32 or workspace.numel() < GUIDANCE_WORKSPACE_FLOATS:
+        raise ValueError(f"ltxmi.guidance_step_: workspace must hold {GUIDANCE_WORKSPACE_FLOATS} fp32 values")
     if cond_mask is None:
         check(lib.ltxmi_guidance_step_bf16(_ptr(noise_pred), n, num_conds, guidance_scale, stg_scale, rescaling_scale,
                                            int(do_cfg), int(do_stg), int(do_rescale), _ptr(latents), int(is_bf16),

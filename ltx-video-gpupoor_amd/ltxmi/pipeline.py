@@ -246,7 +246,7 @@ class LTXVideoPipeline:
                  sample_conditioning_posterior: bool = True, timesteps: Optional[List[float]] = None,
                  guidance_timesteps: Optional[List[float]] = None, skip_initial_inference_steps: int = 0,
                  skip_final_inference_steps: int = 0, strength: float = 1.0, joint_pass: bool = True,
-                 stg_row_dedup: bool = True):
+                 stg_row_dedup: bool = True, dead_row_elimination: bool = True):
         """``latents``: (b, c, f, h, w) as in the reference -- re-noised to the first timestep
         (t0 * noise + (1 - t0) * latents, :688-707) -- or, as an extension for tests, (b, N, c) patchified
         initial noise used as is.  ``stg_row_dedup``: the STG "perturbed" row has the text row's inputs, so it
@@ -276,27 +276,40 @@ class LTXVideoPipeline:
         do_cfg = any(x > 1.0 for x in gs_tab)
         do_stg = any(x > 0.0 for x in stg_tab)
         do_rescale = any(x != 1.0 for x in rs_tab)
-        num_conds = 1 + int(do_cfg) + int(do_stg)
 
-        skip_masks = None
-        if do_stg and skip_tab is not None:                                              # :1016-1026
-            cache = {}
-            skip_masks = []
-            for blocks in skip_tab:
-                key = tuple(blocks)
-                if key not in cache:
-                    cache[key] = tr.create_skip_layer_mask(batch_size, num_conds, num_conds - 1, list(blocks))
-                skip_masks.append(cache[key])
+        # Rows of the batch per step.  The reference keeps num_conds constant and zeroes the scales of the
+        # steps that should not use a guidance (:980-983); a row whose scale is zero at a step does not reach
+        # that step's result (:1183-1222), so it is not computed here (``dead_row_elimination``; bit-identical:
+        # every kernel computes a row independently of the others).
+        def rows_for(i):
+            if not dead_row_elimination:
+                return do_cfg, do_stg
+            return (do_cfg and gs_tab[i] > 1.0), (do_stg and stg_tab[i] > 0.0)
 
-        embeds, mask = prompt_embeds, prompt_attention_mask                              # :1035-1051
-        if do_cfg:
-            embeds = torch.cat([negative_prompt_embeds, embeds], dim=0)
-            mask = torch.cat([negative_prompt_attention_mask, mask], dim=0)
-        if do_stg:
-            embeds = torch.cat([embeds, prompt_embeds], dim=0)
-            mask = torch.cat([mask, prompt_attention_mask], dim=0)
-        embeds = embeds.to(device=device, dtype=tr.dtype)
-        mask = mask.to(device)
+        batches = {}                             # (use_cfg, use_stg) -> (embeds, mask, num_conds)  :1035-1051
+
+        def batch_for(use_cfg, use_stg):
+            key = (use_cfg, use_stg)
+            if key not in batches:
+                e, m = prompt_embeds, prompt_attention_mask
+                if use_cfg:
+                    e = torch.cat([negative_prompt_embeds, e], dim=0)
+                    m = torch.cat([negative_prompt_attention_mask, m], dim=0)
+                if use_stg:
+                    e = torch.cat([e, prompt_embeds], dim=0)
+                    m = torch.cat([m, prompt_attention_mask], dim=0)
+                batches[key] = (e.to(device=device, dtype=tr.dtype), m.to(device), 1 + int(use_cfg) + int(use_stg))
+            return batches[key]
+
+        mask_cache = {}
+
+        def skip_mask_for(i, use_stg, nconds):                                           # :1016-1026
+            if not use_stg or skip_tab is None:
+                return None
+            key = (tuple(skip_tab[i]), nconds)
+            if key not in mask_cache:
+                mask_cache[key] = tr.create_skip_layer_mask(batch_size, nconds, nconds - 1, list(skip_tab[i]))
+            return mask_cache[key]
 
         if latents is not None and latents.dim() == 3:                                   # test hook: given noise
             latents = latents.to(device=device, dtype=latents_dtype).clone()
@@ -318,37 +331,39 @@ class LTXVideoPipeline:
         init_latents = latents.clone() if cond_mask is not None else None
         if cond_mask is not None:
             cond_mask = cond_mask.contiguous()
-            one_minus_mask = (1.0 - cond_mask).expand(num_conds, -1) if num_conds > 1 else (1.0 - cond_mask)
+            one_minus_mask = 1.0 - cond_mask
         frac = pixel_coords.to(torch.float32)
         frac[:, 0] = frac[:, 0] * (1.0 / frame_rate)                                     # :1086-1087
         freqs_cis = tr.precompute_freqs_cis(frac)
 
-        workspace = torch.zeros(8, dtype=torch.float32, device=device)
+        workspace = torch.empty(ops.GUIDANCE_WORKSPACE_FLOATS, dtype=torch.float32, device=device)
         t_dev = torch.tensor(timesteps, dtype=torch.float32, device=device)
         for i, t in enumerate(timesteps):
             if cond_mask is not None and image_cond_noise_scale > 0.0:                   # :1105-1113
                 noise = torch.randn(latents.shape, generator=generator, device=device, dtype=latents.dtype)
                 ops.image_cond_noise_(latents, init_latents, noise, cond_mask, image_cond_noise_scale, t)
+            use_cfg, use_stg = rows_for(i)
+            embeds, mask, nconds = batch_for(use_cfg, use_stg)
             model_in = latents.to(tr.dtype)
-            if num_conds > 1:
-                model_in = model_in.expand(num_conds, -1, -1)
-            current_timestep = t_dev[i].expand(num_conds).unsqueeze(-1)                  # [B_eff, 1]
+            if nconds > 1:
+                model_in = model_in.expand(nconds, -1, -1)
+            current_timestep = t_dev[i].expand(nconds).unsqueeze(-1)                     # [B_eff, 1]
             if cond_mask is not None:                                                    # :1145-1150, [B_eff, N]
-                current_timestep = torch.minimum(current_timestep, one_minus_mask)
+                current_timestep = torch.minimum(current_timestep, one_minus_mask.expand(nconds, -1))
             alias = 0
-            if stg_row_dedup and do_stg and joint_pass:
+            if stg_row_dedup and use_stg and joint_pass:
                 blocks = skip_tab[i] if skip_tab is not None else []
                 alias = min(blocks) if len(blocks) > 0 else len(tr.transformer_blocks)
             noise_pred = tr(model_in, freqs_cis=freqs_cis, encoder_hidden_states=embeds,
                             encoder_attention_mask=mask, timestep=current_timestep, stg_alias_blocks=alias,
-                            skip_layer_mask=None if skip_masks is None else skip_masks[i],
+                            skip_layer_mask=skip_mask_for(i, use_stg, nconds),
                             skip_layer_strategy=skip_layer_strategy,
                             latent_shape=latent_shape[2:], joint_pass=joint_pass, ltxv_model=self, return_dict=False)[0]
             if noise_pred is None:
                 return None
             dt = self.scheduler.host_dt(t)
             ops.guidance_step_(noise_pred, latents, dt, gs_tab[i], stg_tab[i], rs_tab[i],
-                               do_cfg, do_stg, do_rescale, workspace, cond_mask=cond_mask, t=t)   # :1183-1241, 1309-1342
+                               use_cfg, use_stg, do_rescale, workspace, cond_mask=cond_mask, t=t)   # :1183-1241, 1309-1342
             if callback_on_step_end is not None:
                 callback_on_step_end(self, i, t, {})
 

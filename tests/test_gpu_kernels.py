@@ -354,7 +354,7 @@ def test_guidance_step(cfg, stg, resc, lat_dtype):
     truth_v = sched.guidance(npred.float(), nc, gs, stg, resc, do_cfg, do_stg, resc != 1.0)
     truth = lat.float() - dt * truth_v
     d = lat.to(DEV).clone()
-    ws = torch.zeros(8, device=DEV)
+    ws = torch.empty(ops.GUIDANCE_WORKSPACE_FLOATS, device=DEV)
     ops.guidance_step_(npred.to(DEV), d, dt, gs, stg, resc, do_cfg, do_stg, resc != 1.0, ws)
     if lat_dtype == torch.float32:
         torch.testing.assert_close(d.cpu(), truth, rtol=2e-4, atol=2e-5)
@@ -438,7 +438,7 @@ def test_guidance_step_with_conditioning_mask(lat_dtype):
     cur_t = torch.min(t.expand(1).unsqueeze(-1), 1.0 - mask)
     truth = sched.denoising_step(tsch, lat.float(), v, cur_t, mask, t)
     d = lat.to(DEV).clone()
-    ws = torch.zeros(8, device=DEV)
+    ws = torch.empty(ops.GUIDANCE_WORKSPACE_FLOATS, device=DEV)
     ops.guidance_step_(npred.to(DEV), d, dt, 3.0, 1.0, 0.7, True, True, True, ws, cond_mask=mask.to(DEV), t=float(t))
     assert 0.4 < float(t) < 0.8, float(t)
     assert torch.equal(d.cpu()[:, :400], lat[:, :400])                      # frozen tokens are bit-identical

@@ -578,6 +578,14 @@ def test_multiscale_pipeline_two_passes():
     e = rel(out, truth)
     print(f"multi-scale 2 passes: rel L2 {e:.3e}")
     assert e < 2e-2
+    # the exact eliminations (rows whose guidance scale is zero at a step; the STG row before its first
+    # skipped block) do not change a single bit
+    plain = ms(0.5, first, second, height=128, width=192, num_frames=9, prompt_embeds=pos.to(DEV),
+               prompt_attention_mask=pmask.to(DEV), negative_prompt_embeds=neg.to(DEV),
+               negative_prompt_attention_mask=nmask.to(DEV), output_type="latent",
+               generator=torch.Generator(device=DEV).manual_seed(51), stg_row_dedup=False,
+               dead_row_elimination=False)
+    assert torch.equal(plain, out)
 
 
 def test_ulysses_processor_world1_matches_default_processor():
