@@ -17,3 +17,4 @@ from .scheduler import RectifiedFlowScheduler  # noqa: F401
 from .transformer3d import Transformer3DModel, Transformer3DModelOutput  # noqa: F401
 
 __version__ = _lib.lib.ltxmi_version().decode()
+from .ops import set_step_invariant_caching  # noqa: E402,F401

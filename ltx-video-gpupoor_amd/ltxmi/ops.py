@@ -331,6 +331,17 @@ def ndhwc_to_ncdhw(x, c0, C, std=None, mean=None):
     return out
 
 
+# Loop-invariant reuse across denoise steps (caption projection, text keys/values): exact, on by default;
+# bench.py switches it off for its headline number so that every step of the timed region does all the work
+# the reference's step does.
+STEP_INVARIANT_CACHING = True
+
+
+def set_step_invariant_caching(enabled: bool):
+    global STEP_INVARIANT_CACHING
+    STEP_INVARIANT_CACHING = bool(enabled)
+
+
 GUIDANCE_WORKSPACE_FLOATS = 2048      # include/ltxmi.h: LTXMI_GUIDANCE_WORKSPACE_FLOATS
 
 

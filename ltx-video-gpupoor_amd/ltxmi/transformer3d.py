@@ -233,7 +233,21 @@ class Transformer3DModel(nn.Module):
 
         # 2. text projection
         if self.caption_projection is not None:
-            encoder_hidden_states = self.caption_projection(encoder_hidden_states.to(dtype)).view(B, -1, D)
+            # the prompt does not change between the denoise steps of a generation: project it once per
+            # (prompt tensor, weights) and hand the SAME tensor to the blocks, whose text K/V caches key on it
+            ehs = encoder_hidden_states
+            cp = self.caption_projection
+            key = (ehs.data_ptr(), tuple(ehs.shape), ehs.dtype, ehs._version, cp.linear_1.weight.data_ptr(),
+                   cp.linear_1.weight._version, cp.linear_2.weight.data_ptr(), cp.linear_2.weight._version)
+            cache = self.__dict__.setdefault("_caption_cache", {})
+            hit = cache.get(key) if ops.STEP_INVARIANT_CACHING else None
+            if hit is None:
+                if len(cache) >= 4:
+                    cache.clear()
+                hit = (cp(ehs.to(dtype)).view(B, -1, D), ehs)                    # ehs kept alive: no address reuse
+                if ops.STEP_INVARIANT_CACHING:
+                    cache[key] = hit
+            encoder_hidden_states = hit[0]
 
         host_rows = None
         if skip_layer_mask is not None:
