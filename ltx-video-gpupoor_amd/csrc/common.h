@@ -82,6 +82,8 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wa
 // ---- host-side error plumbing --------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// conv_direct.hip: direct 3x3x3 convolution; -1 = shape not taken (use the implicit GEMM)
+int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream);
 
 }  // namespace ltxmi
 

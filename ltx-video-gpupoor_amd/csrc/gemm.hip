@@ -863,6 +863,10 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
     }
     LTXMI_REQUIRE((((uintptr_t)a->x | (uintptr_t)a->w) & 15) == 0 && (((uintptr_t)a->y | (uintptr_t)a->bias) & 7) == 0,
                   LTXMI_ERR_UNSUPPORTED, "ltxmi_conv3d_ndhwc_bf16: misaligned pointer");
+    {
+        const int rc = launch_conv3d_direct(a, (hipStream_t)stream);      // narrow stride-1 layers: direct convolution
+        if (rc >= 0) return rc;
+    }
     GemmParams p;
     p.A = (const uint16_t*)a->x; p.lda = a->Cin;
     p.W = (const uint16_t*)a->w; p.ldw = 9ll * kt * a->Cin;

@@ -641,3 +641,28 @@ def test_gemm_full_size_linearity_ff1_shape():
     rows = exact.all(dim=1)
     if rows.any():
         assert (o3[rows] - lin[rows]).norm() / lin[rows].norm() < 6e-3
+
+
+# ---------------------------------------------------------------- direct convolution path
+@pytest.mark.parametrize("causal,mode,tzero", [(True, "zeros", False), (False, "replicate", False), (False, "zeros", True)])
+@pytest.mark.parametrize("cin,cout,with_add", [(64, 128, False), (128, 256, True)])
+def test_conv3d_direct_path(causal, mode, tzero, cin, cout, with_add):
+    """Shapes the direct (LDS-halo) convolution takes (>= 16384 positions, >= 512 workgroups, Cout % 128 == 0),
+    with partial tiles on every axis (T = 5, H = 36, W = 100 against 2 x 8 x 16 tiles)."""
+    import torch.nn.functional as F
+    from ltxmi import ops
+    B, T, H, W = 2, 5, 36, 100
+    x = rnd(B, cin, T, H, W, seed=110)
+    w = rnd(cout, cin, 3, 3, 3, seed=111, scale=(27 * cin) ** -0.5)
+    b = rnd(cout, seed=112)
+    xf = x.float()
+    if tzero:
+        truth = F.conv3d(xf, w.float(), b.float(), padding=1)
+    else:
+        from oracle import vae as ov
+        truth = ov.causal_conv3d(xf, {"conv.weight": w.float(), "conv.bias": b.float()}, "", causal, mode)
+    add = rnd(B, cout, T, H, W, seed=113) if with_add else None
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
+    out = ops.conv3d(ndhwc(x).to(DEV), wp.to(DEV), b.to(DEV), causal, mode == "replicate",
+                     add=ndhwc(add).to(DEV) if with_add else None, time_pad_zeros=tzero)
+    check(ncdhw(out.cpu()), truth + (add.float() if with_add else 0), what=f"direct conv {cin}->{cout}")
