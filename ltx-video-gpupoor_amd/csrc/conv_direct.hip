@@ -19,6 +19,7 @@ namespace ltxmi {
 
 struct ConvDirectP {
     const uint16_t* x; const uint16_t* w; const uint16_t* bias; uint16_t* y; const uint16_t* add;
+    const uint16_t* res; int res_ch;            // depth-to-space residual (x itself) or NULL
     int B, T, H, W, Cin, Cout;
     int tpad, pad_replicate, tzero;
     int tiles_t, tiles_y, tiles_x, tiles_n;
@@ -33,8 +34,10 @@ constexpr int CD_HALO_BYTES = CD_HALO_ROWS * 128;               // 92160
 constexpr int CD_W_BYTES = 128 * 128;                           // one tap: 128 output channels x 64 input channels
 constexpr int CD_SMEM = CD_HALO_BYTES + 2 * CD_W_BYTES;         // 124928
 
-template <bool ADD>
+// EPI: 0 plain store, 1 y = conv + add, 2 depth-to-space store (+ residual), as the implicit-GEMM kernel's epilogues
+template <int EPI>
 __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
+    constexpr bool ADD = (EPI == 1), D2S = (EPI == 2);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* wst = smem + CD_HALO_BYTES;
@@ -147,6 +150,17 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
                 v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
+                if (D2S && p.res) {
+                    // x_in = repeat(pixel_shuffle(x)): channel c' <- x[(c' mod (Cres/8)) * 8 + pp]   (gemm.hip, EPI_D2S)
+                    const int pos = wm * 64 + i * 16 + frow;
+                    const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1);
+                    const int xx = min(x0 + (pos & 15), p.W - 1);
+                    const int Cp = p.Cout >> 3, pp = n0 / Cp, cp = n0 - pp * Cp + wn * 64 + j * 16 + ecol;
+                    const uint16_t* rrow = p.res + ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.res_ch + pp;
+                    const int cm = p.res_ch >> 3;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bf2f(rrow[((cp + e) % cm) * 8]);
+                }
                 u32x2 o;
                 o[0] = pack_bf16(v[0], v[1]);
                 o[1] = pack_bf16(v[2], v[3]);
@@ -160,7 +174,15 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
             u32x4 w = *(const u32x4*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4));
             const int pos = wm * 64 + c * 32 + row_l;                   // position within the tile
             const int t = t0 + (pos >> 7), yy = y0 + ((pos >> 4) & 7), xx = x0 + (pos & 15);
-            if (t < p.T && yy < p.H && xx < p.W) {
+            if (D2S) {
+                // weight rows are packed (p1 p2 p3)-major: the 128 columns of this block are one pp
+                const int Cp = p.Cout >> 3, pp = n0 / Cp, cp = n0 - pp * Cp + wn * 64 + chunk * 8;
+                const int to = 2 * t + (pp >> 2) - 1, yo = 2 * yy + ((pp >> 1) & 1), xo = 2 * xx + (pp & 1);
+                if (t < p.T && yy < p.H && xx < p.W && to >= 0) {          // the first upsampled frame is dropped
+                    const int64_t opos = (((int64_t)b * (2 * p.T - 1) + to) * (2 * p.H) + yo) * (2 * p.W) + xo;
+                    *(u32x4*)(p.y + opos * Cp + cp) = w;
+                }
+            } else if (t < p.T && yy < p.H && xx < p.W) {
                 const int64_t off = ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.Cout + n0 + wn * 64 + chunk * 8;
                 if (ADD) {
                     const u32x4 r = *(const u32x4*)(p.add + off);
@@ -179,27 +201,34 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     static const int enabled = getenv("LTXMI_CONV_DIRECT") ? atoi(getenv("LTXMI_CONV_DIRECT")) : 1;   // tuning knob
     const int st = a->stride_t > 0 ? a->stride_t : 1, sh = a->stride_hw > 0 ? a->stride_hw : 1;
     const int kt = a->kernel_t > 0 ? a->kernel_t : 3;
-    if (!enabled || a->d2s || st != 1 || sh != 1 || kt != 3 || a->out_T > 0 || a->tpad > 0) return -1;
+    if (!enabled || st != 1 || sh != 1 || kt != 3 || a->out_T > 0 || a->tpad > 0) return -1;
     if (a->Cin % 64 != 0 || a->Cout % 128 != 0 || !a->bias) return -1;
+    if (a->d2s && ((a->Cout / 8) % 128 != 0 || a->add)) return -1;     // a 128-column block must be one (p1 p2 p3)
     const int64_t pos = (int64_t)a->B * a->T * a->H * a->W;
     if (pos < 16384) return -1;
     ConvDirectP p;
     p.x = (const uint16_t*)a->x; p.w = (const uint16_t*)a->w; p.bias = (const uint16_t*)a->bias;
     p.y = (uint16_t*)a->y; p.add = (const uint16_t*)a->add;
+    p.res = a->d2s ? (const uint16_t*)a->residual : nullptr; p.res_ch = a->res_channels;
     p.B = a->B; p.T = a->T; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
     p.tpad = a->causal ? 2 : 1; p.pad_replicate = a->pad_replicate; p.tzero = a->time_pad_zeros ? 1 : 0;
     p.tiles_t = (a->T + CD_TT - 1) / CD_TT; p.tiles_y = (a->H + CD_TY - 1) / CD_TY;
     p.tiles_x = (a->W + CD_TX - 1) / CD_TX; p.tiles_n = a->Cout / 128;
     const int64_t grid = (int64_t)a->B * p.tiles_t * p.tiles_y * p.tiles_x * p.tiles_n;
     if (grid >= (1ll << 31) || grid < 512) return -1;           // needs >= 2 workgroups per CU to fill the chip
-    static bool attr_set[2] = {false, false};
-    if (a->add) {
-        if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)conv3d_direct_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CD_SMEM); attr_set[1] = true; }
-        hipLaunchKernelGGL(conv3d_direct_kernel<true>, dim3((unsigned)grid), dim3(512), CD_SMEM, stream, p);
-    } else {
-        if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)conv3d_direct_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CD_SMEM); attr_set[0] = true; }
-        hipLaunchKernelGGL(conv3d_direct_kernel<false>, dim3((unsigned)grid), dim3(512), CD_SMEM, stream, p);
+#define LTXMI_CD_LAUNCH(E)                                                                                     \
+    {                                                                                                          \
+        static bool attr_set = false;                                                                          \
+        if (!attr_set) {                                                                                       \
+            (void)hipFuncSetAttribute((const void*)conv3d_direct_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, CD_SMEM); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL(conv3d_direct_kernel<E>, dim3((unsigned)grid), dim3(512), CD_SMEM, stream, p);      \
     }
+    if (a->d2s) LTXMI_CD_LAUNCH(2)
+    else if (a->add) LTXMI_CD_LAUNCH(1)
+    else LTXMI_CD_LAUNCH(0)
+#undef LTXMI_CD_LAUNCH
     return check_launch("ltxmi_conv3d_ndhwc_bf16");
 }
 

@@ -666,3 +666,19 @@ def test_conv3d_direct_path(causal, mode, tzero, cin, cout, with_add):
     out = ops.conv3d(ndhwc(x).to(DEV), wp.to(DEV), b.to(DEV), causal, mode == "replicate",
                      add=ndhwc(add).to(DEV) if with_add else None, time_pad_zeros=tzero)
     check(ncdhw(out.cpu()), truth + (add.float() if with_add else 0), what=f"direct conv {cin}->{cout}")
+
+
+@pytest.mark.parametrize("cin,residual,red", [(256, True, 2), (128, False, 1)])
+def test_conv3d_direct_path_depth_to_space(cin, residual, red):
+    """DepthToSpaceUpsample on the direct-convolution path (Cout/8 a multiple of 128, >= 512 workgroups)."""
+    from ltxmi import autoencoder as ae
+    from oracle import vae as ov
+    blk = ae.DepthToSpaceUpsample(3, cin, (2, 2, 2), residual=residual, out_channels_reduction_factor=red,
+                                  spatial_padding_mode="replicate").to(BF)
+    sd = {k: v.detach().float() for k, v in blk.state_dict().items()}
+    x = rnd(1, cin, 5, 36, 100, seed=120)
+    truth = ov.depth_to_space_upsample(x.float(), sd, "", dict(stride=(2, 2, 2), residual=residual, reduction=red),
+                                       False, "replicate")
+    out = blk.to(DEV)(ndhwc(x).to(DEV), causal=False)
+    assert ncdhw(out.cpu()).shape == truth.shape
+    check(ncdhw(out.cpu()), truth, what=f"direct d2s {cin} res={residual} red={red}")
