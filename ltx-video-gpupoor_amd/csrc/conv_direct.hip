@@ -13,6 +13,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace ltxmi {
@@ -32,7 +34,8 @@ constexpr int CD_HT = CD_TT + 2, CD_HY = CD_TY + 2, CD_HX = CD_TX + 2;
 constexpr int CD_HALO_ROWS = CD_HT * CD_HY * CD_HX;            // 720
 constexpr int CD_HALO_BYTES = CD_HALO_ROWS * 128;               // 92160
 constexpr int CD_W_BYTES = 128 * 128;                           // one tap: 128 output channels x 64 input channels
-constexpr int CD_SMEM = CD_HALO_BYTES + 2 * CD_W_BYTES;         // 124928
+constexpr int CD_WSTAGES = 3;
+constexpr int CD_SMEM = CD_HALO_BYTES + CD_WSTAGES * CD_W_BYTES; // 141312
 
 // EPI: 0 plain store, 1 y = conv + add, 2 depth-to-space store (+ residual), as the implicit-GEMM kernel's epilogues
 template <int EPI>
@@ -95,41 +98,64 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Fragments of tap + 1 are fetched while the MFMAs of tap issue (two register sets, the tap loop is
+    // unrolled by two); with three weight stages the weights of tap + 1 have landed before the barrier that
+    // ends tap - 1, and the LDS-DMA of tap + 2 has a whole tap to land.
+    bf16x8 af[2][4][2], bfr[2][4][2];
+    auto read_frags = [&](auto set_tag, int tap) {
+        constexpr int S = decltype(set_tag)::value;
+        const int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        const char* ws = wst + (tap % CD_WSTAGES) * CD_W_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int blk = wm * 4 + i;                                  // (t, y) row of the tile
+            const int row = (((blk >> 3) + dt) * CD_HY + ((blk & 7) + dy)) * CD_HX + dx + frow;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                af[S][i][ks] = *(const bf16x8*)(halo + row * 128 + (((fchunk + 4 * ks) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bfr[S][j][ks] = *(const bf16x8*)(ws + (b_off[j] ^ (ks << 6)));
+    };
+    auto mfmas = [&](auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[S][j][ks], af[S][i][ks], acc[i][j], 0, 0, 0);
+    };
+    using s0_t = std::integral_constant<int, 0>;
+    using s1_t = std::integral_constant<int, 1>;
+    auto sync_all = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // one tap: weights of tap + 2 start streaming, fragments of tap + 1 are read, MFMAs of tap
+    auto tap_body = [&](int tap, int c0, auto cur_tag, auto nxt_tag) {
+        if (tap + 2 < 27) load_w((tap + 2) % CD_WSTAGES, tap + 2, c0);
+        if (tap + 1 < 27) read_frags(nxt_tag, tap + 1);
+        mfmas(cur_tag);
+        sync_all();
+    };
+
     const int nchunks = p.Cin >> 6;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * 64;
         load_halo(c0);
         load_w(0, 0, c0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int tap = 0; tap < 27; ++tap) {
-            const int st = tap & 1;
-            if (tap + 1 < 27) load_w(st ^ 1, tap + 1, c0);
-            const int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            const char* ws = wst + st * CD_W_BYTES;
-            bf16x8 af[4][2], bfr[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int blk = wm * 4 + i;                              // (t, y) row of the tile
-                const int row = (((blk >> 3) + dt) * CD_HY + ((blk & 7) + dy)) * CD_HX + dx + frow;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    af[i][ks] = *(const bf16x8*)(halo + row * 128 + (((fchunk + 4 * ks) ^ (row & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = *(const bf16x8*)(ws + (b_off[j] ^ (ks << 6)));
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        load_w(1, 1, c0);
+        sync_all();
+        read_frags(s0_t{}, 0);
+        for (int tap = 0; tap < 26; tap += 2) {
+            tap_body(tap, c0, s0_t{}, s1_t{});
+            tap_body(tap + 1, c0, s1_t{}, s0_t{});
         }
+        tap_body(26, c0, s0_t{}, s1_t{});
     }
 
     // ---- epilogue: bias (+ add), bf16, through a 4 KB per-wave LDS scratch (the halo is free after the last
