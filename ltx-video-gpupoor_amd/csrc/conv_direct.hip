@@ -80,7 +80,8 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = wrow0 + j * 8;
-            const uint16_t* src = p.w + (int64_t)(n0 + row) * (27 * p.Cin) + tap * p.Cin + c0 + (((lane & 7) ^ (row & 7)) << 3);
+            const int n = min(n0 + row, p.Cout - 1);                      // rows past Cout: recomputed, never stored
+            const uint16_t* src = p.w + (int64_t)n * (27 * p.Cin) + tap * p.Cin + c0 + (((lane & 7) ^ (row & 7)) << 3);
             glds16(src, wst + stage * CD_W_BYTES + (wave * 2 + j) * 1024);
         }
     };
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     const int ecol = (lane >> 4) * 4;
     u32x2 bias_v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bias_v[j] = *(const u32x2*)(p.bias + n0 + wn * 64 + j * 16 + ecol);
+    for (int j = 0; j < 4; ++j) bias_v[j] = *(const u32x2*)(p.bias + min(n0 + wn * 64 + j * 16 + ecol, p.Cout - 4));
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
                     const int64_t opos = (((int64_t)b * (2 * p.T - 1) + to) * (2 * p.H) + yo) * (2 * p.W) + xo;
                     *(u32x4*)(p.y + opos * Cp + cp) = w;
                 }
-            } else if (t < p.T && yy < p.H && xx < p.W) {
+            } else if (t < p.T && yy < p.H && xx < p.W && n0 + wn * 64 + chunk * 8 < p.Cout) {
                 const int64_t off = ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.Cout + n0 + wn * 64 + chunk * 8;
                 if (ADD) {
                     const u32x4 r = *(const u32x4*)(p.add + off);
@@ -228,8 +229,8 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     const int st = a->stride_t > 0 ? a->stride_t : 1, sh = a->stride_hw > 0 ? a->stride_hw : 1;
     const int kt = a->kernel_t > 0 ? a->kernel_t : 3;
     if (!enabled || st != 1 || sh != 1 || kt != 3 || a->out_T > 0 || a->tpad > 0) return -1;
-    if (a->Cin % 64 != 0 || a->Cout % 128 != 0 || !a->bias) return -1;
-    if (a->d2s && ((a->Cout / 8) % 128 != 0 || a->add)) return -1;     // a 128-column block must be one (p1 p2 p3)
+    if (a->Cin % 64 != 0 || a->Cout % 8 != 0 || !a->bias) return -1;
+    if (a->d2s && (a->Cout % 1024 != 0 || a->add)) return -1;          // a 128-column block must be one (p1 p2 p3)
     const int64_t pos = (int64_t)a->B * a->T * a->H * a->W;
     if (pos < 16384) return -1;
     ConvDirectP p;
@@ -239,7 +240,7 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     p.B = a->B; p.T = a->T; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
     p.tpad = a->causal ? 2 : 1; p.pad_replicate = a->pad_replicate; p.tzero = a->time_pad_zeros ? 1 : 0;
     p.tiles_t = (a->T + CD_TT - 1) / CD_TT; p.tiles_y = (a->H + CD_TY - 1) / CD_TY;
-    p.tiles_x = (a->W + CD_TX - 1) / CD_TX; p.tiles_n = a->Cout / 128;
+    p.tiles_x = (a->W + CD_TX - 1) / CD_TX; p.tiles_n = (a->Cout + 127) / 128;
     const int64_t grid = (int64_t)a->B * p.tiles_t * p.tiles_y * p.tiles_x * p.tiles_n;
     if (grid >= (1ll << 31) || grid < 512) return -1;           // needs >= 2 workgroups per CU to fill the chip
 #define LTXMI_CD_LAUNCH(E)                                                                                     \
