@@ -231,8 +231,6 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     if (!enabled || st != 1 || sh != 1 || kt != 3 || a->out_T > 0 || a->tpad > 0) return -1;
     if (a->Cin % 64 != 0 || a->Cout % 8 != 0 || !a->bias) return -1;
     if (a->d2s && (a->Cout % 1024 != 0 || a->add)) return -1;          // a 128-column block must be one (p1 p2 p3)
-    const int64_t pos = (int64_t)a->B * a->T * a->H * a->W;
-    if (pos < 16384) return -1;
     ConvDirectP p;
     p.x = (const uint16_t*)a->x; p.w = (const uint16_t*)a->w; p.bias = (const uint16_t*)a->bias;
     p.y = (uint16_t*)a->y; p.add = (const uint16_t*)a->add;
@@ -242,7 +240,9 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     p.tiles_t = (a->T + CD_TT - 1) / CD_TT; p.tiles_y = (a->H + CD_TY - 1) / CD_TY;
     p.tiles_x = (a->W + CD_TX - 1) / CD_TX; p.tiles_n = (a->Cout + 127) / 128;
     const int64_t grid = (int64_t)a->B * p.tiles_t * p.tiles_y * p.tiles_x * p.tiles_n;
-    if (grid >= (1ll << 31) || grid < 512) return -1;           // needs >= 2 workgroups per CU to fill the chip
+    // one workgroup per CU is resident: below ~half the CUs the implicit GEMM's smaller tiles fill the chip better
+    static const int min_grid = getenv("LTXMI_CONV_DIRECT_MIN_GRID") ? atoi(getenv("LTXMI_CONV_DIRECT_MIN_GRID")) : 128;   // tuning knob
+    if (grid >= (1ll << 31) || grid < min_grid) return -1;
 #define LTXMI_CD_LAUNCH(E)                                                                                     \
     {                                                                                                          \
         static bool attr_set = false;                                                                          \
