@@ -183,6 +183,9 @@ typedef struct ltxmi_conv3d_args {
     int32_t kernel_t, time_pad_zeros;
 } ltxmi_conv3d_args;
 
+/* Two implementations behind this entry, chosen by shape: a direct convolution with the input halo
+ * resident in LDS (stride 1, kernel_t 3, >= 128 workgroups) and an implicit GEMM (everything else).
+ * Requirements for both: Cin % 64 == 0, Cout % 8 == 0, 16-byte aligned x / w. */
 int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* args, void* stream);
 
 /* PixelNorm (pixel_norm.py:5-12, eps 1e-8) -> optional (1+scale)*x+shift per (batch, channel)
