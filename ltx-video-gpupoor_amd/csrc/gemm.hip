@@ -821,7 +821,8 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
     static const int force_tile = getenv("LTXMI_GEMM_TILE") ? atoi(getenv("LTXMI_GEMM_TILE")) : 0;   // tuning knob
     if (force_tile == 128) return launch_tile<128, 128, 2, 2, 0>(p, epi, s, "ltxmi_gemm_bf16");
-    if (a->M >= 1024 && a->N >= 256 && t256 >= 384) {
+    static const long persist_min = getenv("LTXMI_GEMM_PERSIST_MIN_TILES") ? atol(getenv("LTXMI_GEMM_PERSIST_MIN_TILES")) : 128;   // tuning knob (measured: 128 > 256 > 384 for M = 4992 .. 9984)
+    if (a->M >= 1024 && a->N >= 256 && t256 >= persist_min) {
         const bool fits32 = ((int64_t)a->M * a->ldc * 2 < (1ll << 32)) && ((int64_t)256 * a->lda * 2 < (1ll << 31)) &&
                             ((int64_t)256 * a->ldw * 2 < (1ll << 31));
         if (a->K >= 128 && fits32 && force_tile != 256)
