@@ -27,25 +27,17 @@
 // an L2 stream the same K/V at the same time.
 #include <type_traits>
 
-#include "common.h"
+#include "attention.h"
 
 namespace ltxmi {
-
-struct AttnParams {
-    const uint16_t* q; int64_t q_sb, q_sl;
-    const uint16_t* k; int64_t k_sb, k_sl;
-    const uint16_t* v; int64_t v_sb, v_sl;
-    uint16_t* o; int64_t o_sb, o_sl;
-    const float* bias; int64_t bias_sb;
-    int B, H, Lq, Lk;
-    float scale_log2e;   // softmax_scale * log2(e)
-    int q_tiles;         // ceil(Lq / 128)
-};
 
 constexpr int KV_TILE = 64;
 constexpr int Q_PER_WAVE = 32;
 constexpr int Q_PER_WG = 128;
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef LTXMI_ATTN_PIPE
+#define LTXMI_ATTN_PIPE 1
+#endif
 #ifndef LTXMI_ATTN_QB
 #define LTXMI_ATTN_QB 2
 #endif
@@ -521,6 +513,13 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     // where two blocks of accumulators do not fit the register file at 2 waves per SIMD)
     const int64_t wg256 = (int64_t)a->B * a->H * ((a->Lq + 255) / 256);
     if (a->head_dim == 64) {
+#if LTXMI_ATTN_PIPE
+        // large self-attention: the software-pipelined LDS-DMA kernel (attention_pipe.hip)
+        if (wg256 >= 512 && !a->key_bias) {
+            const int rc = launch_attn_pipe(p, s);
+            if (rc != -1) return rc;
+        }
+#endif
         if (wg256 >= 512 && !a->key_bias) return launch<64, false, ATTN_QB_BIG>(p, s);
         return a->key_bias ? launch<64, true, 1>(p, s) : launch<64, false, 1>(p, s);
     }

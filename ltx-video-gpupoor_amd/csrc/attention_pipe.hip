@@ -1,0 +1,429 @@
+// attention_pipe.hip -- software-pipelined flash attention forward for the large self-attention
+// shapes of the DiT (head_dim 64, no key bias): the kernel behind pay_attention()'s eager branch
+// (wan/modules/attention.py:99-116,344-347 of the reference) when there is enough work to fill the chip.
+//
+// Same arithmetic as attention.hip (swapped product S^T = K Q^T with the query on the lane, online
+// softmax in registers, O^T += V^T P^T with P straight from the accumulator registers, row sums on
+// the matrix pipe) -- what changes is WHEN things are issued:
+//
+//   * A wave owns two 32-row query blocks A and B and runs them half a key tile apart.  One key
+//     tile is two segments; in each the VALU does the softmax of one block while the matrix pipe
+//     runs the other block's products:
+//         segment 1:  softmax A(t)      ||  row sums B(t-1), QK^T B(t),   PV B(t-1)
+//         segment 2:  softmax B(t)      ||  row sums A(t),   QK^T A(t+1), PV A(t)
+//     At head_dim 64 the VALU (exp2 + fma + cvt per score) needs slightly MORE issue cycles than
+//     the MFMAs of the same scores need pipe cycles, so every MFMA is issued with five VALU
+//     instructions behind it and neither pipe ever waits for a whole phase of the other.  The
+//     interleave is written out in the source, chunk by chunk, and pinned with sched_barrier.
+//   * K / V tiles go HBM -> LDS by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction) into
+//     two rings of four 8-KiB slots, K three tiles ahead and V two, behind a counted vmcnt: no
+//     staging registers, no ds_write, and no VMEM/LDS-store issue slots taken from the softmax.
+//     The swizzles of both LDS images (attention.hip) are applied to the per-lane SOURCE address.
+//   * One s_barrier per key tile.
+#include <type_traits>
+
+#include "attention.h"
+
+namespace ltxmi {
+
+namespace pipe {
+
+// Diagnostic build only (-DLTXMI_ATTN_STAMPS, tools/attn_stamps.py): s_memtime stamps around the sections of
+// an iteration, summed per wave into a debug buffer.  No stamp executes in the product build.
+#ifdef LTXMI_ATTN_STAMPS
+#define STAMP(i)                                                                               \
+    do {                                                                                       \
+        unsigned long long t_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        st.acc[i] += t_ - st.prev;                                                             \
+        st.prev = t_;                                                                          \
+    } while (0)
+struct Stamps { unsigned long long prev; unsigned long long acc[8]; };
+__device__ unsigned long long* g_attn_stamps = nullptr;
+#else
+#define STAMP(i) do { } while (0)
+struct Stamps {};
+#endif
+
+constexpr int DH = 64;
+constexpr int KV_TILE = 64;
+constexpr int ROW_BYTES = DH * 2;
+constexpr int TILE_BYTES = KV_TILE * DH * 2;     // 8 KiB: one K or V tile
+constexpr int RING = 4;
+constexpr int SMEM = 2 * RING * TILE_BYTES;      // K ring | V ring = 64 KiB
+constexpr int Q_PER_WG = 256;                    // 4 waves x 2 blocks x 32 rows
+
+struct Blk {
+    f32x16 s[2];     // S^T accumulators: keys 0..31 / 32..63 of the tile (rows), query on the lane
+    f32x16 o[2];     // O^T accumulators: head-dim rows 0..31 / 32..63
+    u32x4 pf[4];     // P^T fragments of the last finished softmax (B operand of the PV product), packed bf16 pairs
+    bf16x8 q[4];     // Q^T fragments (B operand of the QK^T product), k-steps of 16
+    f32x4 l;         // row sums (ones-MFMA accumulator): lanes 0..15, registers 0 / 1 = query n / n + 16
+    float m;         // running row max (raw scores)
+};
+
+struct Lane {
+    int lane, r, hh;
+    int k_rd[2];     // byte offset of K row 32 kb + r inside a K slot
+    int k_sw0;       // swizzle of that row
+    int v_rd;        // byte offset of this lane's transposed-read address inside a V slot
+};
+
+// One segment: VALU = softmax of X's pending scores (X.s -> X.pf, X.m, rescale of X.o / X.l);
+// matrix pipe = Y's row sums and PV with Y's pending P against the V slot `vs`, and Y's next
+// scores against the K slot `ks`.
+template <bool TAIL>
+__device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const char* vs, const Lane& L,
+                                        const bf16x8& ones, float c, int key0, int Lk, Stamps& st, int st0) {
+    // ---- head: K fragments of the whole slot (8 x ds_read_b128), Y's row sums, X's row max
+    bf16x8 kf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        kf[j] = *(const bf16x8*)(ks + L.k_rd[j >> 2] + (((2 * (j & 3) + L.hh) ^ L.k_sw0) << 4));
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) Y.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Y.pf[sp]), Y.l, 0, 0, 0);
+
+    if (TAIL) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = key0 + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * L.hh;
+                if (key >= Lk) X.s[kb][e] = -INFINITY;
+            }
+    }
+    float mt;
+    {
+        auto max3 = [](float a, float b, float c3) { return fmaxf(fmaxf(a, b), c3); };
+        float l1[11];
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            l1[g] = max3(X.s[0][3 * g], X.s[0][3 * g + 1], X.s[0][3 * g + 2]);
+            l1[5 + g] = max3(X.s[1][3 * g], X.s[1][3 * g + 1], X.s[1][3 * g + 2]);
+        }
+        l1[10] = max3(X.s[0][15], X.s[1][15], l1[0]);
+        const float a = max3(l1[1], l1[2], l1[3]), b2 = max3(l1[4], l1[5], l1[6]), c2 = max3(l1[7], l1[8], l1[9]);
+        mt = fmaxf(max3(a, b2, c2), l1[10]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+        mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float m_new = fmaxf(X.m, mt);
+    // the O-wide rescale is a real, rarely taken wave-uniform branch (the running max settles after
+    // the first few tiles)
+    if (__any(m_new != X.m)) {
+        asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
+        const float alpha = fast_exp2((X.m - m_new) * c);
+        X.l[0] *= alpha;
+        X.l[1] *= __shfl(alpha, (L.lane + 16) & 63, 64);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) X.o[d][e] *= alpha;
+        X.m = m_new;
+    }
+    const float nmoff = -X.m * c;
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(st0);
+
+    // ---- 16 chunks: one 32x32x16 MFMA, the LDS reads of a later MFMA, and two scores' worth of
+    // softmax (2 fma, 2 exp2, 1 cvt_pk) each
+    bf16x8 vf[8];
+    float pp0 = 0.f, pp1 = 0.f;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < 8) {
+            const int kb = j >> 2, s = j & 3;
+            if (s == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Y.s[kb][e] = 0.f;
+            }
+            Y.s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], Y.q[s], Y.s[kb], 0, 0, 0);
+            // V^T fragment of PV MFMA j (k-step sp = j >> 1, head-dim block d = j & 1)
+            const char* base = vs + L.v_rd + (2 * (j >> 1) * 2 + (j & 1)) * 512;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 2 * 512));
+            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            vf[j] = __builtin_bit_cast(bf16x8, both);
+        } else {
+            const int jj = j - 8, sp = jj >> 1, d = jj & 1;
+            Y.o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jj], __builtin_bit_cast(bf16x8, Y.pf[sp]), Y.o[d], 0, 0, 0);
+        }
+        // softmax of two scores; the pair is packed one chunk later (a v_cvt_pk right behind the v_exp
+        // it reads costs an s_nop: transcendental -> VALU hazard)
+        const int kb = j >> 3, e0 = 2 * (j & 7);
+        const float p0 = fast_exp2(__builtin_fmaf(X.s[kb][e0], c, nmoff));
+        const float p1 = fast_exp2(__builtin_fmaf(X.s[kb][e0 + 1], c, nmoff));
+        if (j > 0) {
+            const int jp = j - 1, kbp = jp >> 3, ep = 2 * (jp & 7);
+            // (the empty asm pins the conversion to this chunk: instruction selection otherwise gathers
+            // all sixteen v_cvt_pk of a segment behind its last MFMA)
+            uint32_t pw = pack_bf16(pp0, pp1);
+            asm volatile("" : "+v"(pw));
+            X.pf[2 * kbp + (ep >> 3)][(ep & 7) >> 1] = pw;
+        }
+        pp0 = p0;
+        pp1 = p1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    X.pf[3][3] = pack_bf16(pp0, pp1);
+    STAMP(st0 + 1);
+}
+
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* kring = smem;
+    char* vring = smem + RING * TILE_BYTES;
+
+    const int tid = threadIdx.x;
+    Lane L;
+    L.lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    L.r = L.lane & 31;
+    L.hh = L.lane >> 5;
+
+    // ---- XCD-aware work id (bijective chunking): an XCD walks whole (batch, head) pairs
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qn = nwg >> 3, rn = nwg & 7;
+    const int work = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
+    const int bh = work / p.q_tiles, qt = work % p.q_tiles;
+    const int b = bh / p.H, head = bh % p.H;
+
+    const uint16_t* qb = p.q + (int64_t)b * p.q_sb + head * DH;
+    const uint16_t* kb_ = p.k + (int64_t)b * p.k_sb + head * DH;
+    const uint16_t* vb = p.v + (int64_t)b * p.v_sb + head * DH;
+    uint16_t* ob = p.o + (int64_t)b * p.o_sb + head * DH;
+
+    // ---- LDS-DMA sources.  One descriptor per operand (base = this (batch, head)'s first row,
+    // num_records = up to the end of its last row): key rows past Lk are out of range and arrive as zeros.
+    // The DMA is issued from inline asm: for a builtin LDS-DMA hipcc puts s_waitcnt vmcnt(0) in front of the
+    // next transposed LDS read (it cannot tell the slots apart), which would drain the ring every segment.
+    // Completion is counted by hand instead (vmcnt(4) at the end of an iteration, then the barrier).
+    auto make_desc = [](const void* base, int64_t bytes) {
+        const uint64_t a = (uint64_t)base;
+        return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)bytes, 0x00020000u};
+    };
+    const u32x4 k_desc = make_desc(kb_, ((int64_t)(p.Lk - 1) * p.k_sl + DH) * 2);
+    const u32x4 v_desc = make_desc(vb, ((int64_t)(p.Lk - 1) * p.v_sl + DH) * 2);
+    // wave w moves pieces 2w, 2w+1 (8 key rows = 1 KiB each) of every K and V tile.
+    //   K image: row r, 16-byte chunk c at slot c ^ ((r >> 1) & 7); lane l of a piece writes row l >> 3, slot l & 7
+    //   V image: [8 key][32 col] sub-tiles of 512 B; lane l writes sub-tile l >> 5 (column half), key (l >> 2) & 7, chunk l & 3
+    uint32_t k_voff[2], v_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = 2 * wave + j;
+        const int krow = 8 * piece + (L.lane >> 3);
+        const int kchunk = (L.lane & 7) ^ ((krow >> 1) & 7);
+        k_voff[j] = (uint32_t)((krow * (int)p.k_sl + 8 * kchunk) * 2);
+        const int vrow = 8 * piece + ((L.lane >> 2) & 7);
+        const int vchunk = 4 * (L.lane >> 5) + (L.lane & 3);
+        v_voff[j] = (uint32_t)((vrow * (int)p.v_sl + 8 * vchunk) * 2);
+    }
+    const uint32_t k_tile_step = (uint32_t)(KV_TILE * (int)p.k_sl * 2), v_tile_step = (uint32_t)(KV_TILE * (int)p.v_sl * 2);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    // two pieces (this wave's share of one tile) per statement; M0 = LDS byte address of the piece
+    auto dma2 = [&](const u32x4& desc, uint32_t lds_addr, uint32_t voff0, uint32_t voff1) {
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %1, %4, 0 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %2, %4, 0 offen lds\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff0), "v"(voff1), "s"(lds_addr), "s"(desc)
+            : "memory", "scc");
+    };
+    auto dma_k = [&](int t) {
+        const uint32_t dst = lds0 + (uint32_t)((t & (RING - 1)) * TILE_BYTES + 2 * wave * 1024);
+        const uint32_t toff = (uint32_t)t * k_tile_step;
+        dma2(k_desc, dst, k_voff[0] + toff, k_voff[1] + toff);
+    };
+    auto dma_v = [&](int t) {
+        const uint32_t dst = lds0 + (uint32_t)((RING + (t & (RING - 1))) * TILE_BYTES + 2 * wave * 1024);
+        const uint32_t toff = (uint32_t)t * v_tile_step;
+        dma2(v_desc, dst, v_voff[0] + toff, v_voff[1] + toff);
+    };
+
+    const int nt = (p.Lk + KV_TILE - 1) / KV_TILE;
+    const int n_full = p.Lk / KV_TILE;
+    dma_k(0); dma_v(0); dma_k(1); dma_v(1); dma_k(2);
+
+    // ---- per-lane LDS read offsets (attention.hip's images)
+    L.k_rd[0] = L.r * ROW_BYTES;
+    L.k_rd[1] = (32 + L.r) * ROW_BYTES;
+    L.k_sw0 = (L.r >> 1) & 7;                       // swz(32 + r) == swz(r)
+    {
+        const int g16 = L.lane >> 4, i16 = L.lane & 15;
+        L.v_rd = (4 * (g16 >> 1) + (i16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+    }
+
+    // ---- state.  Block B's "pending" P of tile -1 is zero and multiplies V slot 3, which is zero-filled.
+    Blk A, Bk;
+    bf16x8 ones;
+    {
+        const bool on = ((L.lane & 15) == 0 && ((L.lane >> 4) & 1) == 0) || ((L.lane & 15) == 1 && ((L.lane >> 4) & 1) == 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = on ? (__bf16)1.0f : (__bf16)0.0f;
+    }
+    auto init = [&](Blk& X, int blk) {
+        const int row = qt * Q_PER_WG + wave * 64 + 32 * blk + L.r;
+        const int q_ld = row < p.Lq ? row : p.Lq - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) X.q[s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * L.hh);
+        X.m = -INFINITY;
+        X.l = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) X.pf[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { X.o[d][e] = 0.f; X.s[d][e] = 0.f; }
+    };
+    init(A, 0);
+    init(Bk, 1);
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *(u32x4*)(vring + 3 * TILE_BYTES + tid * 32) = z;
+        *(u32x4*)(vring + 3 * TILE_BYTES + tid * 32 + 16) = z;
+    }
+    // (the builtin, not asm: hipcc must KNOW the Q loads have landed, or it waits for them with a counted
+    // vmcnt at their first use inside the loop -- which then drains the LDS-DMA ring every iteration)
+    __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // S_A(0)
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 kf = *(const bf16x8*)(kring + L.k_rd[kb2] + (((2 * s + L.hh) ^ L.k_sw0) << 4));
+            A.s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, A.q[s], A.s[kb2], 0, 0, 0);
+        }
+
+    const float c = p.scale_log2e;
+    using no_tail = std::integral_constant<bool, false>;
+    using with_tail = std::integral_constant<bool, true>;
+    Stamps st;
+#ifdef LTXMI_ATTN_STAMPS
+    for (int i = 0; i < 8; ++i) st.acc[i] = 0;
+    { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory"); st.prev = t0_; }
+#endif
+    auto iteration = [&](int t, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(0);
+        dma_k(t + 3);
+        dma_v(t + 2);
+        STAMP(1);
+        segment<TAIL>(A, Bk, kring + (t & 3) * TILE_BYTES, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2);
+        segment<TAIL>(Bk, A, kring + ((t + 1) & 3) * TILE_BYTES, vring + (t & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 4);
+        // everything issued before this iteration's four pieces has landed: K(t+2), V(t+1)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(6);
+    };
+    for (int t = 0; t < n_full; ++t) iteration(t, no_tail{});
+    if (n_full < nt) iteration(n_full, with_tail{});
+
+#ifdef LTXMI_ATTN_STAMPS
+    if (g_attn_stamps && L.lane == 0 && blockIdx.x < 4096) {
+        for (int i = 0; i < 7; ++i) g_attn_stamps[(blockIdx.x * 4 + wave) * 8 + i] = st.acc[i];
+        g_attn_stamps[(blockIdx.x * 4 + wave) * 8 + 7] = (unsigned long long)nt;
+    }
+#endif
+    // ---- drain: block B's last row sums and PV
+    {
+        const char* vs = vring + ((nt - 1) & 3) * TILE_BYTES;
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) Bk.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Bk.pf[sp]), Bk.l, 0, 0, 0);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const char* base = vs + L.v_rd + (2 * sp * 2 + d) * 512;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 2 * 512));
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                Bk.o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), __builtin_bit_cast(bf16x8, Bk.pf[sp]), Bk.o[d], 0, 0, 0);
+            }
+    }
+    // the out-of-range pieces of tiles >= nt are still landing (as zeros): drain them before the
+    // rings become the output scratch
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: O = O^T / l, through a per-wave LDS scratch so that rows leave whole (attention.hip)
+    auto store = [&](Blk& X, int blk) {
+        const float l0 = __shfl(X.l[0], L.r & 15, 64), l1 = __shfl(X.l[1], L.r & 15, 64);
+        const float inv = 1.0f / ((L.r & 16) ? l1 : l0);
+        char* scr = smem + (wave * 2 + blk) * (32 * ROW_BYTES);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w[0] = pack_bf16(X.o[d][4 * g + 0] * inv, X.o[d][4 * g + 1] * inv);
+                w[1] = pack_bf16(X.o[d][4 * g + 2] * inv, X.o[d][4 * g + 3] * inv);
+                const int chunk = 4 * d + g;
+                *(u32x2*)(scr + L.r * ROW_BYTES + ((chunk ^ (L.r & 7)) << 4) + L.hh * 8) = w;
+            }
+        const int q0 = qt * Q_PER_WG + wave * 64 + 32 * blk;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = t * 8 + (L.lane >> 3), chunk = L.lane & 7;
+            const u32x4 w = *(const u32x4*)(scr + row * ROW_BYTES + ((chunk ^ (row & 7)) << 4));
+            if (q0 + row < p.Lq) *(u32x4*)(ob + (int64_t)(q0 + row) * p.o_sl + chunk * 8) = w;
+        }
+    };
+    store(A, 0);
+    store(Bk, 1);
+}
+
+}  // namespace pipe
+
+#ifdef LTXMI_ATTN_STAMPS
+extern "C" int ltxmi_debug_set_attn_stamps(void* buf) {
+    unsigned long long* b = (unsigned long long*)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(pipe::g_attn_stamps), &b, sizeof(b));
+}
+#endif
+
+#ifndef LTXMI_ATTN_PIPE_OCC
+#define LTXMI_ATTN_PIPE_OCC 2
+#endif
+
+int launch_attn_pipe(AttnParams p, hipStream_t stream) {
+    // the buffer descriptors address a (batch, head)'s K / V rows with 32-bit byte offsets
+    const int64_t k_span = ((int64_t)(p.Lk + 4 * pipe::KV_TILE) * p.k_sl + pipe::DH) * 2;
+    const int64_t v_span = ((int64_t)(p.Lk + 4 * pipe::KV_TILE) * p.v_sl + pipe::DH) * 2;
+    if (k_span >= (1ll << 31) || v_span >= (1ll << 31)) return -1;
+    auto kern = pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool cached = dev >= 0 && dev < 64;
+    if (!cached || !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, pipe::SMEM) != hipSuccess) {
+            set_error("ltxmi_attention_fwd_bf16: cannot reserve %d bytes of LDS", pipe::SMEM);
+            return LTXMI_ERR_LAUNCH;
+        }
+        if (cached) attr_set[dev] = true;
+    }
+    p.q_tiles = (p.Lq + pipe::Q_PER_WG - 1) / pipe::Q_PER_WG;
+    const int64_t grid = (int64_t)p.B * p.H * p.q_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pipe::SMEM, stream, p);
+    return check_launch("ltxmi_attention_fwd_bf16");
+}
+
+}  // namespace ltxmi

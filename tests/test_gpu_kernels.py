@@ -165,6 +165,24 @@ def test_attention_online_softmax_rescale_branch():
     check(out, attn_truth(q, k, v), what="rescale branch")
 
 
+@pytest.mark.parametrize("Lq,Lk,spike", [(256, 1, False), (256, 64, False), (300, 65, False), (257, 130, False),
+                                         (256, 200, False), (512, 448, True), (256, 1029, True)])
+def test_attention_pipelined_kernel_edges(Lq, Lk, spike):
+    """Shapes with >= 512 query tiles of 256 rows take the software-pipelined LDS-DMA kernel
+    (attention_pipe.hip).  Its edges: a single (ragged) key tile, exactly one full tile, one full + a ragged
+    tile, key tiles whose ring slots are never filled, ragged query tiles, and the rescale branch with the
+    running max jumping late (block A and block B of a wave at different tiles)."""
+    from ltxmi import ops
+    B, H, dh = 8, 64 if Lq <= 256 else 32, 64
+    q, k, v = rnd(B, Lq, H, dh, seed=40), rnd(B, Lk, H, dh, seed=41), rnd(B, Lk, H, dh, seed=42)
+    if spike:
+        k[:, Lk - 30] = q[:, 5] * 3.0           # last tile, hits rows of block A (rows 0..31 of wave 0)
+        k[:, Lk // 2] = q[:, 40] * 2.0          # block B
+        k[:, 70] = q[:, 100] * 2.5
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    check(out, attn_truth(q, k, v), what=f"pipelined attention Lq{Lq} Lk{Lk}")
+
+
 def test_pay_attention_seam_contract():
     from ltxmi import pay_attention
     B, L, H, dh = 2, 130, 2, 64
