@@ -315,6 +315,8 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
 #ifdef LTXMI_ATTN_STAMPS
     for (int i = 0; i < 8; ++i) st.acc[i] = 0;
     { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory"); st.prev = t0_; }
+    unsigned long long rt0_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0_)::"memory");
 #endif
     auto iteration = [&](int t, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
@@ -335,9 +337,12 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     if (n_full < nt) iteration(n_full, with_tail{});
 
 #ifdef LTXMI_ATTN_STAMPS
+    unsigned long long rt1_;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_)::"memory");
     if (g_attn_stamps && L.lane == 0 && blockIdx.x < 4096) {
         for (int i = 0; i < 7; ++i) g_attn_stamps[(blockIdx.x * 4 + wave) * 8 + i] = st.acc[i];
-        g_attn_stamps[(blockIdx.x * 4 + wave) * 8 + 7] = (unsigned long long)nt;
+        // low 32 bits: key tiles; high 32 bits: elapsed s_memrealtime ticks (100 MHz) of the loop
+        g_attn_stamps[(blockIdx.x * 4 + wave) * 8 + 7] = (unsigned long long)nt | ((rt1_ - rt0_) << 32);
     }
 #endif
     // ---- drain: block B's last row sums and PV

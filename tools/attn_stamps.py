@@ -37,8 +37,12 @@ for _ in range(3):
     assert lib.ltxmi_attention_fwd_bf16(ctypes.byref(a), stream) == 0
 torch.cuda.synchronize()
 d = dbg.view(-1, 8).cpu()
-d = d[d[:, 7] > 0].double()
-nt = d[:, 7:8]
+d = d[d[:, 7] > 0]
+rt = (d[:, 7] >> 32).double()
+nt = (d[:, 7:8] & 0xffffffff).double()
+d = d.double()
+clk = d[:, :7].sum(dim=1) / rt * 100e6
+print(f"in-kernel clock (sum of s_memtime sections / s_memrealtime): median {float(clk.median()) / 1e9:.3f} GHz")
 per = d[:, :7] / nt
 names = ["barrier", "dma issue", "seg1 head", "seg1 chunks", "seg2 head", "seg2 chunks", "vmcnt wait"]
 med = per.median(dim=0).values
