@@ -10,15 +10,23 @@ CFG-star/STG/rescale + Euler update.  `value` = steps/s over all ranks.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU (RCCL only for the barrier / max-reduce of the clock); each rank
-denoises its own video (replicas; "scaling": "weak").  The JSON line also carries:
-  roofline      the dominant kernel of this workload (the FF up-projection GEMM, MFMA-bound):
-                algorithmic FLOP per launch / average launch time from HIP events recorded on
-                the launch stream inside the timed region
-  attention     the self-attention kernel at this workload and at the north-star stress shape
-                (N = 98304, 1 layer, B = 1): TFLOP/s and fraction of the bf16 MFMA peak on QK^T
-  vae_decode    frames/s of CausalVideoAutoencoder.decode for the same video (z [1,128,13,16,24])
+N > 1: one process per GPU.  `value` = replicas (every rank denoises its own video, RCCL only for the
+barrier / max-reduce of the clock; "scaling": "weak").  The same run then times the sequence-sharded mode the
+north star names (ONE video, tokens sharded over the ranks, Ulysses all-to-all inside self-attention,
+ltxmi/distributed.py) and reports it in the same line under "ulysses" ("scaling": "strong").
+The JSON line also carries:
+  roofline      the dominant kernel of this workload = the self-attention kernel (28 launches per step, the
+                largest single share of a step; MFMA-bound): algorithmic FLOP per launch / average launch time
+                from HIP events recorded on the launch stream inside the timed region
+  roofline_gemm the same for the FF up-projection GEMM (the largest GEMM instance)
+  step_ms       median / p10 / p90 of the timed steps (HIP events per step)
+  b_eff_1       the same step with ONE cond (no CFG / STG rows)
+  attention     the self-attention kernel at the north-star stress shape (N = 98304, 1 layer, B = 1), at config 3's
+                N = 13376 and at config 4's Wan shape [1, 32760, 12, 128] (+ cross-attention, 512 text keys)
+  vae_decode    frames/s of CausalVideoAutoencoder.decode for the same video (z [1,128,13,16,24]) and for
+                config 5 (z [1,128,33,23,40] -> 257 frames of 1280 x 720, z-tiled by 4 latent frames)
   cpu_baseline  the CPU oracle (oracle/dit.py, fp32, all host cores) on a bounded sample
+Every extra leg checks its output (finite + a band of rows / a second implementation) before it reports a time.
 """
 import argparse
 import json
@@ -40,10 +48,26 @@ N_TOK = GRID[0] * GRID[1] * GRID[2]  # 4992
 NUM_CONDS = 3
 
 
+def fractional_coords(device):
+    """What LTXVideoPipeline hands to precompute_freqs_cis (pipeline_ltx_video.py:1086-1088): seconds on the time
+    axis (25 fps, causal fix), pixels on y / x.  Product-side helpers only: nothing under oracle/ is used outside
+    the cpu_baseline leg."""
+    from ltxmi.patchifier import SymmetricPatchifier, latent_to_pixel_coords_from_factors
+    coords = SymmetricPatchifier(1).get_latent_coords(*GRID, 1, device)
+    pc = latent_to_pixel_coords_from_factors(coords, (8, 32, 32), causal_fix=True).to(torch.float32)
+    pc[:, 0] = pc[:, 0] * (1.0 / 25.0)
+    return pc
+
+
 def build_transformer(device, layers=L, seed=0):
     import ltxmi
-    from oracle.dit import default_2b_config
-    cfg = dict(default_2b_config(), num_layers=layers)
+    from ltxmi.loading import NATIVE_2B_TRANSFORMER_CONFIG       # OURS_TRANSFORMER_CONFIG, diffusers_config_mapping.py:74-105
+    keep = ("num_attention_heads", "attention_head_dim", "in_channels", "out_channels", "num_layers", "cross_attention_dim",
+            "caption_channels", "attention_bias", "activation_fn", "norm_elementwise_affine", "norm_eps", "qk_norm",
+            "standardization_norm", "positional_embedding_type", "positional_embedding_theta",
+            "positional_embedding_max_pos", "timestep_scale_multiplier")
+    cfg = {k: NATIVE_2B_TRANSFORMER_CONFIG[k] for k in keep}
+    cfg.update(adaptive_norm="single_scale_shift", num_layers=layers)
     torch.manual_seed(seed)
     with torch.device(device):
         m = ltxmi.Transformer3DModel(**cfg)
@@ -69,7 +93,7 @@ class StepRunner:
     def __init__(self, device):
         import ltxmi
         from ltxmi import ops
-        from oracle import sched
+        from ltxmi.scheduler import RectifiedFlowScheduler
         self.ops = ops
         self.ltxmi = ltxmi
         self.m, self.cfg = build_transformer(device)
@@ -78,14 +102,16 @@ class StepRunner:
         self.mask = torch.cat([nmask, mask, mask])
         g = torch.Generator(device=device).manual_seed(1)
         self.latents = torch.randn(1, N_TOK, C_LAT, generator=g, device=device, dtype=torch.float32)
-        frac = sched.fractional_coords(*GRID, 1, 25.0).to(device)
-        self.freqs = self.m.precompute_freqs_cis(frac)
+        self.freqs = self.m.precompute_freqs_cis(fractional_coords(device))
         self.skip = self.m.create_skip_layer_mask(1, NUM_CONDS, NUM_CONDS - 1, [19])
         self.ws = torch.empty(ops.GUIDANCE_WORKSPACE_FLOATS, device=device)
-        ts = sched.set_timesteps(40, (1, C_LAT) + GRID)
+        sch = RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1)       # OURS_SCHEDULER_CONFIG
+        sch.set_timesteps(40, samples_shape=(1, C_LAT) + GRID, device="cpu")
+        ts = sch.timesteps
         self.t = float(ts[10])
         self.dt = float(ts[10] - ts[11])
         self.t_dev = torch.full((NUM_CONDS, 1), self.t, device=device)
+        self.t_dev1 = torch.full((1, 1), self.t, device=device)
 
         class Holder:
             _interrupt = False
@@ -96,6 +122,15 @@ class StepRunner:
         from ltxmi import distributed as sp
         sp.enable_sequence_parallel(self.m)
         self.sp = sp
+
+    @torch.no_grad()
+    def step_one_cond(self):
+        """B_eff = 1: the text row only (no CFG, no STG; guidance scale 1 leaves the prediction as it is)."""
+        x = self.latents.to(torch.bfloat16)
+        noise_pred = self.m(x, freqs_cis=self.freqs, encoder_hidden_states=self.embeds[1:2],
+                            encoder_attention_mask=self.mask[1:2], timestep=self.t_dev1, latent_shape=GRID,
+                            ltxv_model=self.holder, return_dict=False)[0]
+        self.ops.guidance_step_(noise_pred, self.latents, self.dt, 1.0, 0.0, 1.0, False, False, False, self.ws)
 
     @torch.no_grad()
     def step(self, stg_alias_blocks=0):
@@ -116,51 +151,110 @@ class StepRunner:
         self.ops.guidance_step_(noise_pred, self.latents, self.dt, 3.0, 1.0, 0.7, True, True, True, self.ws)
 
 
-def time_attention(device, n_tok, iters, B=1):
+def pct(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
+
+
+def attention_band_check(q, k, v, out, what, rows=64):
+    """A band of query rows against plain fp32 torch on the GPU (outside any timed region): the legs below must
+    not report the time of a kernel that produced garbage."""
+    assert torch.isfinite(out.float()).all(), f"{what}: non-finite attention output"
+    n = q.shape[1]
+    for r0 in (0, max(0, n - rows)):
+        qs = q[:, r0:r0 + rows].float().permute(0, 2, 1, 3)                  # [B,H,r,dh]
+        sc = torch.matmul(qs, k.float().permute(0, 2, 3, 1)) * (q.shape[-1] ** -0.5)
+        ref = torch.matmul(torch.softmax(sc, dim=-1), v.float().permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+        err = float((out[:, r0:r0 + rows].float() - ref).norm() / ref.norm())
+        assert err < 2e-2, f"{what}: rows {r0}..{r0 + rows} differ from fp32 attention by {err:.3e}"
+
+
+def time_attention(device, n_tok, iters, B=1, heads=H, dh=DH, lk=None):
     from ltxmi import ops
     g = torch.Generator(device=device).manual_seed(3)
-    qkv = torch.randn(B, n_tok, 3, H, DH, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
-    out = torch.empty(B, n_tok, H, DH, device=device, dtype=torch.bfloat16)
-    ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out=out)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    qkv = torch.randn(B, n_tok, 3, heads, dh, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    if lk is not None:                                       # cross-attention: lk keys
+        k, v = k[:, :lk].contiguous(), v[:, :lk].contiguous()
+    out = torch.empty(B, n_tok, heads, dh, device=device, dtype=torch.bfloat16)
+    ops.attention(q, k, v, out=out)
+    attention_band_check(q, k, v, out, f"attention N={n_tok} Lk={k.shape[1]} heads={heads} dh={dh}")
+    ts = []
     for _ in range(iters):
-        ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], out=out)
-    e1.record()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.attention(q, k, v, out=out)
+        e1.record()
+        ts.append((e0, e1))
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    flops = 4.0 * B * n_tok * n_tok * D                 # QK^T + PV
+    ts = [a.elapsed_time(b) for a, b in ts]
+    ms = pct(ts, 0.5)
+    flops = 4.0 * B * n_tok * k.shape[1] * heads * dh       # QK^T + PV
     tf = flops / ms / 1e9
-    return {"tokens": n_tok, "batch": B, "ms": round(ms, 3), "tflops": round(tf, 1),
-            "qk_frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-            "algorithmic_bytes": 8 * B * n_tok * D, "note": "QK^T and PV run at the same rate: "
-            "fraction = (4 N^2 D / t) / peak = (2 N^2 D / (t/2)) / peak"}
+    return {"tokens": n_tok, "keys": k.shape[1], "batch": B, "heads": heads, "head_dim": dh, "ms": round(ms, 3),
+            "ms_p10": round(pct(ts, 0.1), 3), "ms_p90": round(pct(ts, 0.9), 3), "iters": iters,
+            "tflops": round(tf, 1), "qk_frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+            "algorithmic_bytes": 2 * B * heads * dh * (2 * n_tok + 2 * k.shape[1]),
+            "note": "QK^T and PV run at the same rate: fraction = (4 Lq Lk H dh / t) / peak = (2 Lq Lk H dh / (t/2)) / peak"}
 
 
-def time_vae(device, iters):
+def time_vae(device, iters, grid=GRID, z_tile=0):
+    """CausalVideoAutoencoder.decode of z [1,128,*grid] with the 0.9.5+-style timestep-conditioned decoder
+    (create_video_autoencoder_demo_config(128), causal_video_autoencoder.py:1302-1338), timestep 0.05.
+    z_tile > 0: the reference's z-tiling (vae.py:365-402, tiles of z_tile + 1 latent frames, blends).
+    The untiled result is cross-checked against the same decode with every convolution as an implicit GEMM
+    (a second, independently tested implementation) before anything is timed."""
     import ltxmi
-    from oracle import vae as ov
-    cfg = ov.demo_config(128)                           # the 0.9.5+-style timestep-conditioned decoder
+    from ltxmi import ops
+    cfg = {"_class_name": "CausalVideoAutoencoder", "dims": 3, "in_channels": 3, "out_channels": 3, "latent_channels": 128,
+           "encoder_blocks": [], "blocks": [["res_x", {"num_layers": 4}], ["compress_all", {"residual": True}],
+                                            ["res_x", {"num_layers": 4}], ["compress_all", {"residual": True}],
+                                            ["res_x", {"num_layers": 4}], ["compress_all", {"residual": True}],
+                                            ["res_x", {"num_layers": 4}]],
+           "scaling_factor": 1.0, "norm_layer": "pixel_norm", "patch_size": 4, "latent_log_var": "uniform",
+           "use_quant_conv": False, "causal_decoder": False, "timestep_conditioning": True,
+           "spatial_padding_mode": "replicate", "decoder_base_channels": 128, "build_encoder": False}
     torch.manual_seed(5)
     with torch.device(device):
         vae = ltxmi.CausalVideoAutoencoder.from_config(dict(cfg))
     vae = vae.to(dtype=torch.bfloat16).eval()
     vae.decoder.timestep_scale_multiplier.data = vae.decoder.timestep_scale_multiplier.data.float()
-    z = torch.randn(1, C_LAT, *GRID, device=device).to(torch.bfloat16)
+    z = torch.randn(1, C_LAT, *grid, device=device).to(torch.bfloat16)
     ts = torch.tensor([0.05], device=device)
+    if z_tile:
+        vae.enable_z_tiling(z_tile)
+    check = {}
     with torch.no_grad():
         img = ltxmi.vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)
+        assert torch.isfinite(img.float()).all(), "non-finite VAE decode output"
+        if not z_tile:
+            old = ops.CONV_ALGO
+            try:
+                ops.CONV_ALGO = 1
+                ref = ltxmi.vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)
+            finally:
+                ops.CONV_ALGO = old
+            err = float((img.float() - ref.float()).norm() / ref.float().norm())
+            # two independent bf16 renderings, each ~8e-3 from fp32 truth: an indexing error would be 1e-1 .. 1
+            assert err < 1.5e-2, f"VAE decode: direct-convolution and implicit-GEMM paths differ by {err:.3e}"
+            check = {"rel_l2_vs_implicit_gemm_decode": round(err, 5)}
+            del ref
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        times = []
         for _ in range(iters):
+            t0 = time.perf_counter()
             img = ltxmi.vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)
-        torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    dt = pct(times, 0.5)
     frames = img.shape[2]
-    return {"frames": frames, "shape": list(img.shape), "ms_per_decode": round(dt * 1e3, 2),
-            "frames_per_s": round(frames / dt, 2), "algorithmic_tflop": 24.4,
-            "tflops": round(24.4 / dt, 1)}
+    out = {"latent": [1, C_LAT] + list(grid), "frames": frames, "shape": list(img.shape), "z_tile": z_tile,
+           "ms_per_decode": round(dt * 1e3, 2), "ms_p10": round(pct(times, 0.1) * 1e3, 2),
+           "ms_p90": round(pct(times, 0.9) * 1e3, 2), "iters": iters, "frames_per_s": round(frames / dt, 2)}
+    if not z_tile and tuple(grid) == GRID:
+        out.update({"algorithmic_tflop": 24.4, "tflops": round(24.4 / dt, 1)})
+    out.update(check)
+    return out
 
 
 def cpu_baseline():
@@ -195,16 +289,44 @@ def cpu_baseline():
                       f"extrapolated x{L} blocks x{NUM_CONDS} conds"}
 
 
+def timed_steps(step_fn, steps, dist):
+    """EXACTLY `steps` calls of step_fn bracketed by barrier + synchronize on both sides; returns (elapsed seconds by
+    the host clock, per-step milliseconds from HIP events on the launch stream)."""
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(steps):
+        step_fn()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+
+
+def max_over_ranks(x, dist, device):
+    if dist is None:
+        return x
+    t = torch.tensor([x], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-extras", action="store_true", help="skip attention-stress / VAE / CPU legs")
-    ap.add_argument("--parallelism", choices=["replicas", "ulysses"], default="replicas",
-                    help="replicas (default): every rank denoises its own video, no data-path collective, weak scaling; "
-                         "ulysses: ONE video, tokens sharded over the ranks, all-to-all inside self-attention "
-                         "(ltxmi.distributed), strong scaling")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-extras", action="store_true", help="skip the B_eff-1 / attention-shape / VAE / CPU legs")
+    ap.add_argument("--parallelism", choices=["both", "replicas", "ulysses"], default="both",
+                    help="N > 1 only.  replicas: every rank denoises its own video, no data-path collective (weak scaling, "
+                         "this is `value`); ulysses: ONE video, tokens sharded over the ranks, all-to-all inside "
+                         "self-attention (ltxmi.distributed, strong scaling); both (default): `value` from replicas and "
+                         "the Ulysses run reported in the same line under \"ulysses\"")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,8 +337,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    ulysses = args.parallelism == "ulysses"
-    if world > 1 or ulysses:
+    ulysses_only = args.parallelism == "ulysses"
+    if world > 1 or ulysses_only:
         import torch.distributed as dist
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -228,95 +350,127 @@ def main():
     from ltxmi import ops
     ops.set_step_invariant_caching(False)     # headline: every timed step does all the work of the reference's step
     runner = StepRunner(device)
-    if ulysses:
+
+    def measure(ulysses):
+        sp = world if ulysses else 1                          # token (and, inside attention, head) shards
+        M = NUM_CONDS * N_TOK // sp
+        key_ff1 = ("gemm", M, FF, D, ops.EPI_GELU_TANH)
+        key_attn = ("attention", NUM_CONDS, H // sp, N_TOK, N_TOK, DH)
+        for _ in range(args.warmup):
+            runner.step()
+        ops.watch_launches([key_ff1, key_attn])
+        elapsed, per_step = timed_steps(runner.step, args.steps, dist)
+        times = ops.launch_times_ms()
+        ops.watch_launches(None)
+        elapsed = max_over_ranks(elapsed, dist, device)
+        assert torch.isfinite(runner.latents).all(), "non-finite latents after the timed steps"
+        ff1, at = times.get(key_ff1, []), times.get(key_attn, [])
+        ff1_ms, at_ms = sum(ff1) / max(len(ff1), 1), sum(at) / max(len(at), 1)
+        return {"elapsed": elapsed, "per_step": per_step, "sp": sp, "M": M, "ff1_ms": ff1_ms, "n_ff1": len(ff1),
+                "at_ms": at_ms, "n_at": len(at)}
+
+    uly = None
+    if ulysses_only:
         runner.enable_ulysses()
-    sp = world if ulysses else 1                              # token (and, inside attention, head) shards
-    M = NUM_CONDS * N_TOK // sp
-    key_ff1 = ("gemm", M, FF, D, ops.EPI_GELU_TANH)
-    key_attn = ("attention", NUM_CONDS, H // sp, N_TOK, N_TOK, DH)
-
-    for _ in range(args.warmup):
-        runner.step()
-    ops.watch_launches([key_ff1, key_attn])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    times = ops.launch_times_ms()
-    ops.watch_launches(None)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    assert torch.isfinite(runner.latents).all(), "non-finite latents after the timed steps"
-    ms_per_step = elapsed / args.steps * 1e3
-    value = (1 if ulysses else world) * args.steps / elapsed
+        r = measure(True)
+    else:
+        r = measure(False)
+        if world > 1 and args.parallelism == "both":
+            runner.enable_ulysses()
+            uly = measure(True)
+            runner.sp = None
+    ms_per_step = r["elapsed"] / args.steps * 1e3
+    value = (1 if ulysses_only else world) * args.steps / r["elapsed"]
 
     if rank == 0:
-        ff1 = times.get(key_ff1, [])
-        ff1_ms = sum(ff1) / max(len(ff1), 1)
+        sp, M = r["sp"], r["M"]
         ff1_flop = 2.0 * M * FF * D
-        achieved = ff1_flop / (ff1_ms * 1e-3) / 1e12 if ff1_ms > 0 else 0.0
-        traffic = None
+        ff1_tf = ff1_flop / (r["ff1_ms"] * 1e-3) / 1e12 if r["ff1_ms"] > 0 else 0.0
+        at_flop = 4.0 * NUM_CONDS * N_TOK * N_TOK * (D // sp)
+        at_tf = at_flop / (r["at_ms"] * 1e-3) / 1e12 if r["at_ms"] > 0 else 0.0
+        traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("ff1_gemm_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath))
             except Exception:
-                traffic = None
-        at = times.get(key_attn, [])
-        at_ms = sum(at) / max(len(at), 1)
-        at_tf = 4.0 * NUM_CONDS * N_TOK * N_TOK * (D // sp) / (at_ms * 1e-3) / 1e12 if at_ms > 0 else 0.0
+                traffic = {}
+        tnote = ("static: HBM-side bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                 "command committed as " + traffic.get("source", "profiles/traffic.json") +
+                 " (gfx950 corrections applied); not re-measured in this run")
         line = {
             "metric": "denoise-steps/sec + VAE-decode frames/sec, LTX-Video 768x512x97f at 1/8 GPU",
             "value": round(value, 4), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
-            "scaling": "strong" if ulysses else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong" if ulysses_only else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "LTX-Video 2B t2v 768x512x97, one denoise step = Transformer3DModel.forward "
                                    "(28 layers, D 2048, 32x64 heads, N 4992 tokens, T 256) at B_eff 3 "
                                    "(CFG + STG rows) + fused guidance/Euler; random-init weights",
-                       "tokens": N_TOK, "b_eff": NUM_CONDS, "layers": L, "parallelism": (f"ulysses sp{world}" if ulysses else f"replicas x{world}"),
+                       "tokens": N_TOK, "b_eff": NUM_CONDS, "layers": L,
+                       "parallelism": (f"ulysses sp{world}" if ulysses_only else f"replicas x{world}"),
                        "algorithmic_tflop_per_step": 66.4},
             "step_tflops": round(66.4 / (ms_per_step * 1e-3), 1),
-            "roofline": {"kernel": f"gemm_bf16_nt_persistent_kernel<256,256,2,4,GELU_TANH> (ff.net.0, M={M} N=8192 K=2048)",
-                         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-                         "traffic": traffic, "launch_ms": round(ff1_ms, 4), "launches_timed": len(ff1),
-                         "algorithmic_flop_per_launch": ff1_flop},
-            "attention": {"workload": {"tokens": N_TOK, "batch": NUM_CONDS, "ms": round(at_ms, 4),
-                                       "tflops": round(at_tf, 1),
-                                       "qk_frac_of_mfma_peak": round(at_tf / MFMA_BF16_PEAK_TFLOPS, 4)}},
+            "step_ms": {"median": round(pct(r["per_step"], 0.5), 3), "p10": round(pct(r["per_step"], 0.1), 3),
+                        "p90": round(pct(r["per_step"], 0.9), 3), "n": len(r["per_step"]),
+                        "note": "HIP events around each timed step on the launch stream"},
+            "roofline": {"kernel": f"attention (ltxmi::pipe::attn_pipe_kernel, self-attention B={NUM_CONDS} H={H // sp} "
+                                   f"N={N_TOK} dh={DH}; 28 launches per step, the largest single share of a step)",
+                         "bound": "mfma", "achieved": round(at_tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(at_tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "traffic": traffic.get("attention_hbm_bytes_per_launch"), "traffic_source": tnote,
+                         "launch_ms": round(r["at_ms"], 4), "launches_timed": r["n_at"],
+                         "algorithmic_flop_per_launch": at_flop,
+                         "algorithmic_bytes_per_launch": 8 * NUM_CONDS * N_TOK * (D // sp)},
+            "roofline_gemm": {"kernel": f"gemm_bf16_nt_persistent_kernel<256,256,2,4,GELU_TANH> (ff.net.0, M={M} N=8192 K=2048)",
+                              "bound": "mfma", "achieved": round(ff1_tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(ff1_tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                              "traffic": traffic.get("ff1_gemm_hbm_bytes_per_launch"), "traffic_source": tnote,
+                              "launch_ms": round(r["ff1_ms"], 4), "launches_timed": r["n_ff1"],
+                              "algorithmic_flop_per_launch": ff1_flop},
         }
-        if not args.no_extras and world == 1:
-            # NOT the headline number: the same step with the STG "perturbed" row taken as a copy of the text row
-            # for the 19 blocks before its first skipped block (bit-identical output, tests/test_gpu_model.py);
-            # ltxmi.LTXVideoPipeline does this by default (stg_row_dedup)
-            ops.set_step_invariant_caching(True)
-            runner.step(stg_alias_blocks=19)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                runner.step(stg_alias_blocks=19)
-            torch.cuda.synchronize()
-            dd = (time.perf_counter() - t1) / args.steps
-            line["pipeline_default"] = {"denoise_steps_per_s": round(1.0 / dd, 4), "ms_per_step": round(dd * 1e3, 2),
-                                        "note": "as ltxmi.LTXVideoPipeline runs a step: STG row taken from the text row "
-                                                "before its first skipped block + prompt K/V projected once per "
-                                                "generation (both exact); not part of `value`"}
-            ops.set_step_invariant_caching(False)
-            del runner
-            torch.cuda.empty_cache()
-            line["attention"]["stress_98304"] = time_attention(device, 98304, 2)
-            line["attention"]["tokens_13376"] = time_attention(device, 13376, 5)
-            line["vae_decode"] = time_vae(device, 2)
-            line["cpu_baseline"] = cpu_baseline()
+        if uly is not None:
+            ums = uly["elapsed"] / args.steps * 1e3
+            line["ulysses"] = {"value": round(args.steps / uly["elapsed"], 4), "unit": "denoise-steps/s (ONE video)",
+                               "scaling": "strong", "ms_per_step": round(ums, 2), "parallelism": f"ulysses sp{world}",
+                               "step_ms": {"median": round(pct(uly["per_step"], 0.5), 3),
+                                           "p10": round(pct(uly["per_step"], 0.1), 3),
+                                           "p90": round(pct(uly["per_step"], 0.9), 3)},
+                               "attention_launch_ms": round(uly["at_ms"], 4),
+                               "note": "same step, tokens sharded N/P per rank, packed q,k,v all-to-all + o all-to-all per "
+                                       "layer over RCCL, final all-gather (ltxmi/distributed.py)"}
+    extras = (not args.no_extras) and world == 1 and not ulysses_only
+    if extras:
+        # B_eff = 1 (report both): the same model, the text row only
+        for _ in range(2):
+            runner.step_one_cond()
+        e1, per1 = timed_steps(runner.step_one_cond, args.steps, None)
+        line["b_eff_1"] = {"denoise_steps_per_s": round(args.steps / e1, 4), "ms_per_step": round(e1 / args.steps * 1e3, 2),
+                           "step_ms": {"median": round(pct(per1, 0.5), 3), "p10": round(pct(per1, 0.1), 3),
+                                       "p90": round(pct(per1, 0.9), 3)},
+                           "algorithmic_tflop_per_step": 22.1}
+        # NOT the headline number: the same step with the STG "perturbed" row taken as a copy of the text row
+        # for the 19 blocks before its first skipped block (bit-identical output, tests/test_gpu_model.py);
+        # ltxmi.LTXVideoPipeline does this by default (stg_row_dedup)
+        ops.set_step_invariant_caching(True)
+        runner.step(stg_alias_blocks=19)
+        ed, _ = timed_steps(lambda: runner.step(stg_alias_blocks=19), args.steps, None)
+        dd = ed / args.steps
+        line["pipeline_default"] = {"denoise_steps_per_s": round(1.0 / dd, 4), "ms_per_step": round(dd * 1e3, 2),
+                                    "note": "as ltxmi.LTXVideoPipeline runs a step: STG row taken from the text row "
+                                            "before its first skipped block + prompt K/V projected once per "
+                                            "generation (both exact); not part of `value`"}
+        ops.set_step_invariant_caching(False)
+        del runner
+        torch.cuda.empty_cache()
+        line["attention"] = {
+            "stress_98304": time_attention(device, 98304, 3),
+            "config3_tokens_13376": time_attention(device, 13376, 20),
+            "config4_wan_self_32760x12x128": time_attention(device, 32760, 20, heads=12, dh=128),
+            "config4_wan_cross_512_keys": time_attention(device, 32760, 20, heads=12, dh=128, lk=512)}
+        line["vae_decode"] = time_vae(device, 20)
+        line["vae_decode_config5"] = time_vae(device, 5, grid=(33, 23, 40), z_tile=4)
+        line["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -74,6 +74,8 @@ typedef struct ltxmi_gemm_args {
     const void* gate_temb;            /* bf16, row g at gate_temb + g*gate_ld               */
     int64_t     gate_ld;
     int32_t     rows_per_group;       /* tokens sharing one modulation row (N_tok / T1)     */
+    int32_t     algo;                 /* 0 = kernel chosen by shape (the product setting); diagnostics:
+                                         128 = 128x128-tile kernel, 256 = non-persistent 256x256 kernel */
 } ltxmi_gemm_args;
 
 int ltxmi_gemm_bf16(const ltxmi_gemm_args* args, void* stream);
@@ -181,6 +183,9 @@ typedef struct ltxmi_conv3d_args {
      * kernel_t = 1: a 3x3 nn.Conv2d applied per frame (w is [Cout, 9*Cin]); time_pad_zeros = 1:
      * nn.Conv3d(padding=1) -- the time axis is padded with zeros instead of replicated frames. */
     int32_t kernel_t, time_pad_zeros;
+    int32_t algo;              /* 0 = implementation chosen by shape (the product setting); 1 = implicit GEMM;
+                                  2 = direct convolution (LTXMI_ERR_UNSUPPORTED if it does not take the shape).
+                                  Used by the parity tests to check the two implementations against each other. */
 } ltxmi_conv3d_args;
 
 /* Two implementations behind this entry, chosen by shape: a direct convolution with the input halo

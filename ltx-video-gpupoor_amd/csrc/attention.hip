@@ -468,11 +468,8 @@ template <int DH, bool HAS_BIAS, int QB>
 static int launch(AttnParams p, hipStream_t stream) {
     using C = AttnCfg<DH>;
     auto kern = attn_fwd_kernel<DH, HAS_BIAS, QB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        attr_set = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (const int rc = reserve_lds((const void*)kern, C::SMEM, &lds_done, "ltxmi_attention_fwd_bf16")) return rc;
     const int q_per_wg = Q_PER_WG * QB;
     p.q_tiles = (p.Lq + q_per_wg - 1) / q_per_wg;
     const int64_t grid = (int64_t)p.B * p.H * p.q_tiles;

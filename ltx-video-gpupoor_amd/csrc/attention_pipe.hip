@@ -414,17 +414,8 @@ int launch_attn_pipe(AttnParams p, hipStream_t stream) {
     const int64_t v_span = ((int64_t)(p.Lk + 4 * pipe::KV_TILE) * p.v_sl + pipe::DH) * 2;
     if (k_span >= (1ll << 31) || v_span >= (1ll << 31)) return -1;
     auto kern = pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC>;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const bool cached = dev >= 0 && dev < 64;
-    if (!cached || !attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, pipe::SMEM) != hipSuccess) {
-            set_error("ltxmi_attention_fwd_bf16: cannot reserve %d bytes of LDS", pipe::SMEM);
-            return LTXMI_ERR_LAUNCH;
-        }
-        if (cached) attr_set[dev] = true;
-    }
+    static unsigned long long lds_done = 0;
+    if (const int rc = reserve_lds((const void*)kern, pipe::SMEM, &lds_done, "ltxmi_attention_fwd_bf16")) return rc;
     p.q_tiles = (p.Lq + pipe::Q_PER_WG - 1) / pipe::Q_PER_WG;
     const int64_t grid = (int64_t)p.B * p.H * p.q_tiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pipe::SMEM, stream, p);

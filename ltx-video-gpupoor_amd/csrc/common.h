@@ -82,6 +82,13 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wa
 // ---- host-side error plumbing --------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// Per-DEVICE launch state (a process may run the DiT on one GPU and the VAE on another):
+//   reserve_lds: hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); `done` is the
+//   kernel's own bit mask of devices (a function-local static of the launcher).  Returns LTXMI_OK or
+//   LTXMI_ERR_LAUNCH with the error text set.
+//   device_cu_count: CUs of the current device (cached per device), <= 0 on failure.
+int reserve_lds(const void* kernel, int bytes, unsigned long long* done, const char* what);
+int device_cu_count(const char* what);
 // conv_direct.hip: direct 3x3x3 convolution; -1 = shape not taken (use the implicit GEMM)
 int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream);
 

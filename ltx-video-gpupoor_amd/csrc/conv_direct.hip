@@ -225,10 +225,9 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
 
 // Returns -1 when the shape is not one this kernel takes (the caller then uses the implicit GEMM).
 int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
-    static const int enabled = getenv("LTXMI_CONV_DIRECT") ? atoi(getenv("LTXMI_CONV_DIRECT")) : 1;   // tuning knob
     const int st = a->stride_t > 0 ? a->stride_t : 1, sh = a->stride_hw > 0 ? a->stride_hw : 1;
     const int kt = a->kernel_t > 0 ? a->kernel_t : 3;
-    if (!enabled || st != 1 || sh != 1 || kt != 3 || a->out_T > 0 || a->tpad > 0) return -1;
+    if (st != 1 || sh != 1 || kt != 3 || a->out_T > 0 || a->tpad > 0) return -1;
     if (a->Cin % 64 != 0 || a->Cout % 8 != 0 || !a->bias) return -1;
     if (a->d2s && (a->Cout % 1024 != 0 || a->add)) return -1;          // a 128-column block must be one (p1 p2 p3)
     ConvDirectP p;
@@ -241,15 +240,15 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     p.tiles_x = (a->W + CD_TX - 1) / CD_TX; p.tiles_n = (a->Cout + 127) / 128;
     const int64_t grid = (int64_t)a->B * p.tiles_t * p.tiles_y * p.tiles_x * p.tiles_n;
     // one workgroup per CU is resident: below ~half the CUs the implicit GEMM's smaller tiles fill the chip better
-    static const int min_grid = getenv("LTXMI_CONV_DIRECT_MIN_GRID") ? atoi(getenv("LTXMI_CONV_DIRECT_MIN_GRID")) : 128;   // tuning knob
-    if (grid >= (1ll << 31) || grid < min_grid) return -1;
+    // (algo = 2 asks for this kernel whatever the grid)
+    constexpr int min_grid = 128;
+    if (grid >= (1ll << 31) || (grid < min_grid && a->algo != 2)) return -1;
 #define LTXMI_CD_LAUNCH(E)                                                                                     \
     {                                                                                                          \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            (void)hipFuncSetAttribute((const void*)conv3d_direct_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, CD_SMEM); \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
+        static unsigned long long lds_done = 0;                                                                \
+        if (const int rc_ = reserve_lds((const void*)conv3d_direct_kernel<E>, CD_SMEM, &lds_done,              \
+                                        "ltxmi_conv3d_ndhwc_bf16"))                                            \
+            return rc_;                                                                                        \
         hipLaunchKernelGGL(conv3d_direct_kernel<E>, dim3((unsigned)grid), dim3(512), CD_SMEM, stream, p);      \
     }
     if (a->d2s) LTXMI_CD_LAUNCH(2)

@@ -699,11 +699,8 @@ static int launch_tile(const GemmParams& p0, int epi, hipStream_t stream, const 
 #define LTXMI_GEMM_LAUNCH(E)                                                                          \
     {                                                                                                 \
         auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_M, WAVES_N, E, MODE>;                                \
-        static bool attr_set = false;                                                                 \
-        if (!attr_set) {                                                                              \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
-            attr_set = true;                                                                          \
-        }                                                                                             \
+        static unsigned long long lds_done = 0;                                                       \
+        if (const int rc_ = reserve_lds((const void*)kern, smem, &lds_done, what)) return rc_;        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, stream, p);                        \
     }
     if constexpr (MODE == 0) {
@@ -730,27 +727,16 @@ static int launch_persistent(const GemmParams& p0, int epi, hipStream_t stream, 
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const int ntiles = p.tiles_m * p.tiles_n;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            set_error("%s: cannot query the device", what);
-            return LTXMI_ERR_LAUNCH;
-        }
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = device_cu_count(what);
+    if (n_cu <= 0) return LTXMI_ERR_LAUNCH;
     const int grid = ntiles < n_cu ? ntiles : n_cu;      // one 8-wave workgroup per CU (all 160 KB of LDS)
     constexpr int threads = WAVES_M * WAVES_N * 64;
     constexpr int smem = 2 * (BM + BN) * BK * 2 + WAVES_M * WAVES_N * 4096;   // 2 stages + epilogue scratch
 #define LTXMI_GEMM_LAUNCH_P(E)                                                                        \
     {                                                                                                 \
         auto kern = gemm_bf16_nt_persistent_kernel<BM, BN, WAVES_M, WAVES_N, E>;                      \
-        static bool attr_set = false;                                                                 \
-        if (!attr_set) {                                                                              \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
-            attr_set = true;                                                                          \
-        }                                                                                             \
+        static unsigned long long lds_done = 0;                                                       \
+        if (const int rc_ = reserve_lds((const void*)kern, smem, &lds_done, what)) return rc_;        \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, stream, p);                        \
     }
     switch (epi) {
@@ -819,9 +805,12 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     // Tile choice: 256x256 (8 waves) when it still fills the 256 CUs, else 128x128 (4 waves,
     // 2 blocks/CU); skinny problems (adaLN tables, text K/V) take the 128x128 path too.
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-    static const int force_tile = getenv("LTXMI_GEMM_TILE") ? atoi(getenv("LTXMI_GEMM_TILE")) : 0;   // tuning knob
+    // a->algo (diagnostics): 0 = by shape, 128 = the 128x128 tile kernel, 256 = the non-persistent 256x256 one
+    const int force_tile = a->algo;
+    LTXMI_REQUIRE(force_tile == 0 || force_tile == 128 || force_tile == 256, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_gemm_bf16: algo %d not in {0, 128, 256}", force_tile);
     if (force_tile == 128) return launch_tile<128, 128, 2, 2, 0>(p, epi, s, "ltxmi_gemm_bf16");
-    static const long persist_min = getenv("LTXMI_GEMM_PERSIST_MIN_TILES") ? atol(getenv("LTXMI_GEMM_PERSIST_MIN_TILES")) : 128;   // tuning knob (measured: 128 > 256 > 384 for M = 4992 .. 9984)
+    constexpr long persist_min = 128;      // measured: 128 > 256 > 384 tiles for M = 4992 .. 9984
     if (a->M >= 1024 && a->N >= 256 && t256 >= persist_min) {
         const bool fits32 = ((int64_t)a->M * a->ldc * 2 < (1ll << 32)) && ((int64_t)256 * a->lda * 2 < (1ll << 31)) &&
                             ((int64_t)256 * a->ldw * 2 < (1ll << 31));
@@ -864,9 +853,12 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
     }
     LTXMI_REQUIRE((((uintptr_t)a->x | (uintptr_t)a->w) & 15) == 0 && (((uintptr_t)a->y | (uintptr_t)a->bias) & 7) == 0,
                   LTXMI_ERR_UNSUPPORTED, "ltxmi_conv3d_ndhwc_bf16: misaligned pointer");
-    {
+    LTXMI_REQUIRE(a->algo >= 0 && a->algo <= 2, LTXMI_ERR_INVALID_ARG, "ltxmi_conv3d_ndhwc_bf16: algo %d not in {0, 1, 2}", a->algo);
+    if (a->algo != 1) {
         const int rc = launch_conv3d_direct(a, (hipStream_t)stream);      // narrow stride-1 layers: direct convolution
         if (rc >= 0) return rc;
+        LTXMI_REQUIRE(a->algo != 2, LTXMI_ERR_UNSUPPORTED,
+                      "ltxmi_conv3d_ndhwc_bf16: algo = 2 (direct convolution) does not take this shape");
     }
     GemmParams p;
     p.A = (const uint16_t*)a->x; p.lda = a->Cin;

@@ -17,7 +17,7 @@ class GemmArgs(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("lda", c_int64), ("W", c_void_p), ("ldw", c_int64), ("bias", c_void_p),
                 ("C", c_void_p), ("ldc", c_int64), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("epilogue", c_int), ("residual", c_void_p), ("ldr", c_int64), ("gate_table", c_void_p),
-                ("gate_temb", c_void_p), ("gate_ld", c_int64), ("rows_per_group", c_int)]
+                ("gate_temb", c_void_p), ("gate_ld", c_int64), ("rows_per_group", c_int), ("algo", c_int)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -36,7 +36,7 @@ class Conv3dArgs(ctypes.Structure):
                 ("causal", c_int), ("pad_replicate", c_int), ("d2s", c_int), ("residual", c_void_p),
                 ("res_channels", c_int), ("add", c_void_p),
                 ("stride_t", c_int), ("stride_hw", c_int), ("tpad", c_int), ("out_T", c_int),
-                ("kernel_t", c_int), ("time_pad_zeros", c_int)]
+                ("kernel_t", c_int), ("time_pad_zeros", c_int), ("algo", c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/ltxmi.h one to one

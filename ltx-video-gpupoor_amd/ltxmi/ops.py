@@ -77,7 +77,7 @@ def _rows(t):
 
 
 def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, gate_table=None, gate_temb=None,
-         rows_per_group=1):
+         rows_per_group=1, algo=0):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  ``a``/``out``/``residual`` may be row-strided 2-D views.
     gate_temb: 2-D view [groups, N] (row stride = gate_ld)."""
     _chk_bf16(a, w, bias, out, residual, gate_table, gate_temb)
@@ -105,6 +105,7 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, gate_table
         args.gate_temb = gate_temb.data_ptr()
         args.gate_ld = gate_temb.stride(0) if gate_temb.dim() == 2 else 0
     args.rows_per_group = rows_per_group
+    args.algo = algo               # 0 = kernel chosen by shape; 128 / 256: diagnostics (include/ltxmi.h)
     tok = _prof_begin(("gemm", M, N, K, epilogue))
     check(lib.ltxmi_gemm_bf16(ctypes.byref(args), _stream()), "ltxmi_gemm_bf16")
     _prof_end(tok)
@@ -213,8 +214,13 @@ def stg_blend_(a, v, m_f32):
     return a
 
 
+# Convolution implementation: 0 = chosen by shape (the product setting), 1 = implicit GEMM, 2 = direct convolution.
+# The parity tests run a decode both ways to check the two implementations against each other.
+CONV_ALGO = 0
+
+
 def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, add=None, out=None,
-           stride=(1, 1, 1), tpad=0, out_T=0, kernel_t=3, time_pad_zeros=False):
+           stride=(1, 1, 1), tpad=0, out_T=0, kernel_t=3, time_pad_zeros=False, algo=None):
     """x [B,T,H,W,Cin] NDHWC; w_packed [Cout, 27*Cin] (tap-major; (p1p2p3, c')-major rows when d2s).
     stride = (st, s, s) with st, s in {1, 2}; tpad / out_T: front time padding and output frames
     when they differ from CausalConv3d's (0 = default); kernel_t = 1: per-frame 3x3 Conv2d
@@ -246,6 +252,7 @@ def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, a
     a.causal, a.pad_replicate, a.d2s = int(causal), int(pad_replicate), int(d2s)
     a.stride_t, a.stride_hw, a.tpad, a.out_T = st, sh, tpad, out_T
     a.kernel_t, a.time_pad_zeros = kernel_t, int(time_pad_zeros)
+    a.algo = CONV_ALGO if algo is None else algo
     if residual is not None:
         a.residual, a.res_channels = residual.data_ptr(), residual.shape[-1]
     if add is not None:

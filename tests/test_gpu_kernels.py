@@ -700,3 +700,95 @@ def test_conv3d_direct_path_depth_to_space(cin, residual, red):
     out = blk.to(DEV)(ndhwc(x).to(DEV), causal=False)
     assert ncdhw(out.cpu()).shape == truth.shape
     check(ncdhw(out.cpu()), truth, what=f"direct d2s {cin} res={residual} red={red}")
+
+
+# ------------------------------------------------ the widths and sizes the bench times (real 0.9.5+ decoder)
+def _crop_bands(T, H, W):
+    """Two corner crops of a [T,H,W] grid, (4, 10, 18) positions each, and for each the slice of crop outputs
+    whose 3x3x3 receptive field lies inside the crop (the volume's own borders are inside the crop, so the
+    reference's padding acts on the crop exactly as on the full tensor)."""
+    near = ((slice(0, 4), slice(0, 10), slice(0, 18)), (slice(0, 3), slice(0, 9), slice(0, 17)))
+    far = ((slice(T - 4, T), slice(H - 10, H), slice(W - 18, W)), (slice(1, 4), slice(1, 10), slice(1, 18)))
+    return near, far
+
+
+@pytest.mark.parametrize("cin,cout,grid,with_add", [(512, 512, (25, 32, 48), True), (1024, 1024, (13, 16, 24), False),
+                                                    (1024, 1024, (4, 16, 64), True)])
+def test_conv3d_direct_full_width_bands(cin, cout, grid, with_add):
+    """The direct convolution at the channel counts of the timed decoder (Cin 512 / 1024: 8 / 16 chunks of 64 input
+    channels per tile) on the bench's own stage grids.  The CPU oracle cannot do 10^11..10^12 FLOP in seconds, but a
+    convolution is local: two corner crops of the full-size result are compared with the oracle run on the crops."""
+    from ltxmi import ops
+    from oracle import vae as ov
+    T, H, W = grid
+    g = torch.Generator(device=DEV).manual_seed(130 + cin)
+    x = torch.randn(1, T, H, W, cin, generator=g, device=DEV).to(BF)                    # NDHWC
+    w = rnd(cout, cin, 3, 3, 3, seed=131, scale=(27 * cin) ** -0.5)
+    b = rnd(cout, seed=132)
+    add = torch.randn(1, T, H, W, cout, generator=g, device=DEV).to(BF) if with_add else None
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
+    out = ops.conv3d(x, wp.to(DEV), b.to(DEV), False, True, add=add, algo=2)             # 2 = the direct kernel, or an error
+    assert torch.isfinite(out.float()).all()
+    for (ct, cy, cx), (vt, vy, vx) in _crop_bands(T, H, W):
+        xc = x[:, ct, cy, cx].permute(0, 4, 1, 2, 3).float().cpu()                       # NCDHW crop
+        truth = ov.causal_conv3d(xc, {"conv.weight": w.float(), "conv.bias": b.float()}, "", False, "replicate")
+        got = out[:, ct, cy, cx].permute(0, 4, 1, 2, 3).float().cpu()
+        if with_add:
+            truth = truth + add[:, ct, cy, cx].permute(0, 4, 1, 2, 3).float().cpu()
+        check(got[:, :, vt, vy, vx], truth[:, :, vt, vy, vx], what=f"direct conv {cin}->{cout} full-size crop")
+    # and the two implementations against each other over the WHOLE tensor
+    ref = ops.conv3d(x, wp.to(DEV), b.to(DEV), False, True, add=add, algo=1)             # implicit GEMM
+    check(out, ref, rel_l2=4e-3, what=f"direct vs implicit GEMM {cin}->{cout}")
+
+
+def test_conv3d_direct_full_width_depth_to_space_band():
+    """DepthToSpaceUpsample 1024 -> 4096 (+ residual) on the bench's first-stage grid 13 x 16 x 24: crop check of the
+    direct kernel's scatter epilogue at full width, and the whole tensor against the implicit GEMM."""
+    from ltxmi import autoencoder as ae, ops
+    from oracle import vae as ov
+    cin, (T, H, W) = 1024, (13, 16, 24)
+    blk = ae.DepthToSpaceUpsample(3, cin, (2, 2, 2), residual=True, out_channels_reduction_factor=2,
+                                  spatial_padding_mode="replicate").to(BF)
+    sd = {k: v.detach().float() for k, v in blk.state_dict().items()}
+    g = torch.Generator(device=DEV).manual_seed(140)
+    x = torch.randn(1, T, H, W, cin, generator=g, device=DEV).to(BF)
+    blk = blk.to(DEV)
+    out = blk(x, causal=False)                                                           # [1, 2T-1, 2H, 2W, 512]
+    assert out.shape == (1, 2 * T - 1, 2 * H, 2 * W, cin // 2) and torch.isfinite(out.float()).all()
+    xc = x[:, 0:4, 0:10, 0:18].permute(0, 4, 1, 2, 3).float().cpu()
+    truth = ov.depth_to_space_upsample(xc, sd, "", dict(stride=(2, 2, 2), residual=True, reduction=2), False, "replicate")
+    got = out[:, 0:5, 0:18, 0:34].permute(0, 4, 1, 2, 3).float().cpu()                   # from input positions [0:3, 0:9, 0:17]
+    check(got, truth[:, :, 0:5, 0:18, 0:34], what="direct d2s 1024->4096 full-size crop")
+    old = ops.CONV_ALGO
+    try:
+        ops.CONV_ALGO = 1
+        ref = blk(x, causal=False)
+    finally:
+        ops.CONV_ALGO = old
+    check(out, ref, rel_l2=4e-3, what="direct vs implicit GEMM d2s 1024->4096")
+
+
+@pytest.mark.parametrize("B,H,N,dh", [(1, 32, 13376, 64), (1, 12, 32760, 128)])
+def test_attention_config_shapes_properties(B, H, N, dh):
+    """Config 3 (N = 13 376, 32 heads of 64) and config 4 (Wan 1.3B: [1, 32760, 12, 128], a ragged last key tile) at
+    full size: softmax rows sum to one, the output is linear in V, and a band of query rows matches the oracle."""
+    from ltxmi import ops
+    g = torch.Generator(device=DEV).manual_seed(150 + dh)
+    q = torch.randn(B, N, H, dh, generator=g, device=DEV).to(BF)
+    k = torch.randn(B, N, H, dh, generator=g, device=DEV).to(BF)
+    v1 = torch.randn(B, N, H, dh, generator=g, device=DEV).to(BF)
+    v2 = torch.randn(B, N, H, dh, generator=g, device=DEV).to(BF)
+    o = ops.attention(q, k, torch.ones_like(v1)).float()
+    assert (o - 1.0).abs().max() < 8e-3
+    o1, o2 = ops.attention(q, k, v1).float(), ops.attention(q, k, v2).float()
+    o3 = ops.attention(q, k, (0.5 * v1.float() + 0.25 * v2.float()).to(BF)).float()
+    lin = 0.5 * o1 + 0.25 * o2
+    assert (o3 - lin).norm() / lin.norm() < 2e-2
+    for rows in (slice(0, 64), slice(N - 70, N)):                    # first tile and the ragged end
+        truth = attn_truth(q[:, rows].cpu(), k.cpu(), v1.cpu())
+        check(o1[:, rows], truth, rel_l2=2e-2, maxrel=6e-2, what=f"attention N{N} dh{dh} rows {rows}")
+    # cross-attention of config 4: 512 text keys, no bias
+    kc, vc = k[:, :512].contiguous(), v1[:, :512].contiguous()
+    oc = ops.attention(q, kc, vc)
+    rows = slice(1000, 1256)
+    check(oc[:, rows], attn_truth(q[:, rows].cpu(), kc.cpu(), vc.cpu()), what=f"cross Lk 512 at N{N} dh{dh}")

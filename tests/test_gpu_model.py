@@ -29,6 +29,23 @@ def rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-12))
 
 
+def maxrel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def assert_parity(out, truth, eager, what):
+    """err(ours) <= err(reference bf16 eager) + RTOL in relative L2, plus an element-wise guard: our largest error
+    (as a fraction of the output range) may not exceed the eager path's largest error by more than half of it + 1 %."""
+    assert torch.isfinite(out.float()).all(), f"{what}: non-finite output"
+    e_ours, e_ref = rel(out, truth), rel(eager, truth)
+    m_ours, m_ref = maxrel(out, truth), maxrel(eager, truth)
+    print(f"{what}: rel L2 ours {e_ours:.3e} / reference-bf16-eager {e_ref:.3e};  max err / range ours {m_ours:.3e} / eager {m_ref:.3e}")
+    assert e_ours <= e_ref + RTOL, (what, e_ours, e_ref)
+    assert m_ours <= 1.5 * m_ref + 1e-2, (what, m_ours, m_ref)
+    return e_ours, e_ref
+
+
 def dit_case(heads, dh, layers, grid, B, T, caption=128, seed=0, per_token=False):
     from oracle import dit, sched
     cfg = dict(dit.default_2b_config(), num_attention_heads=heads, attention_head_dim=dh, num_layers=layers,
@@ -85,10 +102,7 @@ def test_transformer_small(per_token):
     fc = m.precompute_freqs_cis(frac.to(DEV))
     out = m(x.to(DEV), freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV),
             timestep=ts.to(DEV), latent_shape=grid, ltxv_model=_Holder(), return_dict=False)[0]
-    e_ours, e_ref = rel(out, truth), rel(eager, truth)
-    print(f"small per_token={per_token}: ours {e_ours:.3e}  reference-bf16-eager {e_ref:.3e}")
-    assert torch.isfinite(out).all()
-    assert e_ours <= e_ref + RTOL, (e_ours, e_ref)
+    assert_parity(out, truth, eager, f"small per_token={per_token}")
 
 
 @pytest.mark.parametrize("strategy", ["AttentionValues", "AttentionSkip", "TransformerBlock"])
@@ -109,9 +123,7 @@ def test_transformer_stg_strategies(strategy):
     out = m(x.to(DEV), freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV),
             timestep=ts.to(DEV), skip_layer_mask=dmask, skip_layer_strategy=getattr(ltxmi.SkipLayerStrategy, strategy),
             latent_shape=grid, ltxv_model=_Holder(), return_dict=False)[0]
-    e_ours, e_ref = rel(out, truth), rel(eager, truth)
-    print(f"stg {strategy}: ours {e_ours:.3e}  reference-bf16-eager {e_ref:.3e}")
-    assert e_ours <= e_ref + RTOL, (e_ours, e_ref)
+    assert_parity(out, truth, eager, f"stg {strategy}")
     # the perturbed row must differ from the unperturbed one (the mask really took effect)
     assert rel(out[2], out[1]) > 1e-3
 
@@ -186,9 +198,28 @@ def test_transformer_2b_width_two_layers():
             timestep=ts.to(DEV), skip_layer_mask=m.create_skip_layer_mask(1, 3, 2, [1]),
             skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=grid,
             ltxv_model=_Holder(), return_dict=False)[0]
-    e_ours, e_ref = rel(out, truth), rel(eager, truth)
-    print(f"2B-width: ours {e_ours:.3e}  reference-bf16-eager {e_ref:.3e}")
-    assert e_ours <= e_ref + RTOL, (e_ours, e_ref)
+    assert_parity(out, truth, eager, "2B-width, 2 layers, N 1040")
+
+
+def test_transformer_2b_one_block_full_size():
+    """Config 2 at FULL size: 2B widths, N = 4992 tokens (13 x 16 x 24), B_eff = 3 (CFG + STG rows), T = 256 --
+    the tensors the bench times -- through ONE transformer block plus the embeddings and the output head, against
+    the fp32 oracle and the reference's bf16 eager rendering of the same computation."""
+    import ltxmi
+    from oracle import dit
+    grid, B, T = (13, 16, 24), 3, 256
+    cfg, sd32, x, enc, mask, ts, frac = dit_case(32, 64, 1, grid, B, T, caption=4096, seed=16)
+    skip = dit.create_skip_layer_mask(1, 1, 3, 2, [0], torch.float32)
+    truth, eager = run_oracles(cfg, sd32, x, enc, mask, ts, frac, grid, skip_layer_mask=skip,
+                               skip_layer_strategy=dit.ATTENTION_VALUES)
+    m = build_model(cfg, sd32)
+    fc = m.precompute_freqs_cis(frac.to(DEV))
+    out = m(x.to(DEV), freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV),
+            timestep=ts.to(DEV), skip_layer_mask=m.create_skip_layer_mask(1, 3, 2, [0]),
+            skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=grid,
+            ltxv_model=_Holder(), return_dict=False)[0]
+    assert out.shape == (3, 4992, 128)
+    assert_parity(out, truth, eager, "2B-width, 1 block, N 4992, B_eff 3")
 
 
 # ------------------------------------------------------------------------------- VAE
@@ -240,10 +271,7 @@ def test_vae_decode(style):
     out = ltxmi.vae_decode(z.to(DEV), v, True, vae_per_channel_normalize=True,
                            timestep=None if ts is None else ts.to(DEV))
     assert out.shape == truth.shape == (1, 3, 17, 128, 160)
-    e_ours, e_ref = rel(out, truth), rel(eager, truth)
-    print(f"vae {style}: ours {e_ours:.3e}  reference-bf16-eager {e_ref:.3e}")
-    assert torch.isfinite(out).all()
-    assert e_ours <= e_ref + RTOL, (e_ours, e_ref)
+    assert_parity(out, truth, eager, f"vae {style}")
     # decode() contract: asserts on target_shape, DecoderOutput vs tuple (vae.py:357-364,410-413)
     with pytest.raises(AssertionError):
         v.decode(z.to(DEV))
@@ -261,11 +289,54 @@ def test_vae_decode_through_direct_convolution():
     ts = torch.tensor([0.05])
     truth = ov.vae_decode(sd, cfg, z.float(), ts)
     v = build_vae(cfg, sd)
+    sdb = {k: (v.to(BF) if v.is_floating_point() and v.dim() > 0 else v) for k, v in sd.items()}
+    eager = ov.vae_decode(sdb, cfg, z, ts)
     out = ltxmi.vae_decode(z.to(DEV), v, True, vae_per_channel_normalize=True, timestep=ts.to(DEV))
     assert out.shape == truth.shape == (1, 3, 9, 256, 256)
-    e = rel(out, truth)
-    print(f"vae decode through the direct convolution: rel L2 {e:.3e}")
-    assert torch.isfinite(out).all() and e < 1.3e-2        # the reference's own bf16 eager sits at ~1.2e-2 here
+    assert_parity(out, truth, eager, "vae decode through the direct convolution")
+
+
+def test_vae_decode_full_width():
+    """The decoder the bench times: decoder_base_channels = 128 (1024 / 512 / 256 / 128 channels per stage, the
+    d2s 1024 -> 4096 upsampler), on a latent the CPU oracle can decode in seconds."""
+    from oracle import vae as ov
+    import ltxmi
+    cfg, sd = vae_case("b", base=128)
+    z = torch.randn(1, 128, 3, 6, 8, generator=torch.Generator().manual_seed(17)).to(BF)
+    ts = torch.tensor([0.05])
+    truth = ov.vae_decode(sd, cfg, z.float(), ts)
+    sdb = {k: (v.to(BF) if v.is_floating_point() and v.dim() > 0 else v) for k, v in sd.items()}
+    eager = ov.vae_decode(sdb, cfg, z, ts)
+    v = build_vae(cfg, sd)
+    out = ltxmi.vae_decode(z.to(DEV), v, True, vae_per_channel_normalize=True, timestep=ts.to(DEV))
+    assert out.shape == truth.shape == (1, 3, 17, 192, 256)
+    assert_parity(out, truth, eager, "vae decode, base 128")
+
+
+def test_vae_decode_bench_size_both_convolutions_agree():
+    """Config 2's decode (z [1,128,13,16,24] -> 97 x 512 x 768, base 128) is far beyond the CPU oracle.  The decoder is
+    run twice on the GPU -- convolutions chosen by shape (the direct kernel wherever it applies: what the bench times)
+    and all of them as implicit GEMMs -- two independent implementations, each oracle-checked at these widths on
+    crops / small latents (test_gpu_kernels.py), that must agree on the full-size result."""
+    import ltxmi
+    from ltxmi import ops
+    cfg, sd = vae_case("b", base=128)
+    v = build_vae(cfg, sd)
+    z = torch.randn(1, 128, 13, 16, 24, generator=torch.Generator().manual_seed(18)).to(BF).to(DEV)
+    ts = torch.tensor([0.05], device=DEV)
+    out = ltxmi.vae_decode(z, v, True, vae_per_channel_normalize=True, timestep=ts)
+    assert out.shape == (1, 3, 97, 512, 768) and torch.isfinite(out.float()).all()
+    old = ops.CONV_ALGO
+    try:
+        ops.CONV_ALGO = 1
+        ref = ltxmi.vae_decode(z, v, True, vae_per_channel_normalize=True, timestep=ts)
+    finally:
+        ops.CONV_ALGO = old
+    e = rel(out, ref)
+    print(f"bench-size decode, direct vs implicit-GEMM convolutions: rel L2 {e:.3e}")
+    # each path is a bf16 rendering ~8e-3 from the fp32 truth (test_vae_decode_full_width); two INDEPENDENT renderings
+    # differ by up to sqrt(2) times that.  An indexing / padding / chunking error shows up at 1e-1 .. 1.
+    assert e < 1.5e-2 and maxrel(out, ref) < 8e-2
 
 
 def test_vae_tiled_decode_matches_oracle_tiling():

@@ -27,10 +27,9 @@ for (T, H, W, C, Co) in [(49, 64, 96, 256, 256), (97, 128, 192, 128, 128), (25, 
     M, K = T * H * W, 27 * C
     fl = 2.0 * M * Co * K
     for rep in (False, True):
-        ms = timeit(lambda: ops.conv3d(x, w, b, False, rep))
+        ms = timeit(lambda: ops.conv3d(x, w, b, False, rep, algo=1))        # implicit GEMM
         print(f"conv {C}->{Co} @ {T}x{H}x{W} replicate={rep}: {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF", flush=True)
     a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
-    os.environ["LTXMI_GEMM_TILE"] = "256"
-    ms = timeit(lambda: ops.gemm(a, w, b))
-    print(f"dense gemm {M}x{Co}x{K}: {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF (dispatch default)", flush=True)
+    ms = timeit(lambda: ops.gemm(a, w, b, algo=256))
+    print(f"dense gemm {M}x{Co}x{K}: {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF (256x256 tile kernel)", flush=True)
     del a, x, w
