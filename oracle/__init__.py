@@ -14,7 +14,7 @@ and, for the rows SURVEY.md 8f marks "next":
     Encoder / SpaceToDepthDownsample / encode / vae_encode     oracle/vae_encoder.py   (golden G11)
     prepare_conditioning, masked denoising_step, cond. noise   oracle/conditioning.py  (golden G12)
     LatentUpsampler, adain_filter_latent, _upsample_latents    oracle/upsampler.py     (golden G13)
-    retrieve_timesteps, prepare_latents, guidance tables       oracle/pipeline_ctl.py  (golden G14; tables unpinned)
+    retrieve_timesteps, prepare_latents, guidance tables       oracle/pipeline_ctl.py  (golden G14; tables: golden G7)
 
 Who may import it: ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
 leg of ``bench.py``.  The product package (``ltx-video-gpupoor_amd/ltxmi``) must
@@ -42,8 +42,13 @@ Pinning status
   ``DiagonalGaussianDistribution`` (mean / clamped logvar; its ``sample()`` was replaced by the mean
   because the reference draws unseeded noise there) and ``randn_tensor`` (= ``torch.randn``; the
   draws are stored in the fixtures and replayed).  Same status: **parity unpinned** at that boundary.
-* The guidance math (CFG-star / STG / std-rescale) lives inside
-  ``LTXVideoPipeline.__call__`` which cannot run on CPU (hard-coded
-  ``.to("cuda")`` at pipeline_ltx_video.py:1041) -- it is restated line by line and
-  is **parity unpinned**.
+* The guidance math (CFG-star / STG / std-rescale, :1183-1222), the per-step guidance tables (:959-1013) and the
+  loop plumbing of ``LTXVideoPipeline.__call__`` are pinned since round 2 by golden G7 (= SURVEY G7 + G11): the
+  reference's own ``__call__`` run for config 1 (256x256x9, 2 steps, fp32, CPU) on an ``__init__``-less instance; its
+  one GPU-only line, ``negative_prompt_attention_mask.to("cuda")`` (:1041), is satisfied by handing the mask in as a
+  Tensor subclass whose ``.to("cuda")`` stays on the CPU (``oracle/gen/make_golden.py::g7``; nothing of the reference
+  is edited).  ``guidance`` is written for one prompt (B = 1), which is all the reference's CFG-star line is
+  well-formed for: its ``alpha * noise_pred_uncond`` multiplies ``[B, 1]`` by ``[B, N, C]`` (:1199), which for B > 1
+  broadcasts alpha along the TOKEN axis (or fails) instead of per sample; the oracle's ``alpha.view(B, 1, 1)`` is the
+  per-sample reading and coincides with the reference at B = 1 only.
 """

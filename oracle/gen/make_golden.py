@@ -593,7 +593,130 @@ def g14():
     save("g14_pipeline_control", t, dict(meta, shape=list(shape), t0=0.725))
 
 
-CASES = {"g14": g14, "g13": g13, "g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
+@torch.no_grad()
+def g7():
+    """G7 + G11 of SURVEY 8c: the reference's OWN ``LTXVideoPipeline.__call__`` (pipeline_ltx_video.py:762-1307) for
+    config 1 -- 256x256x9, 2 denoise steps, fp32 on the CPU, CFG 3 + STG 1 (skip block 1, AttentionValues) + std-rescale 0.7
+    -- on an instance made without __init__ (tiny reference DiT, the reference scheduler and patchifier).  Captured per
+    step: what the transformer was fed and returned, the guided prediction handed to denoising_step, the latents after
+    the step; plus the final unpatchified latents.  These pin the guidance block (:1183-1222), the per-step guidance
+    tables (:959-1013) and the loop plumbing of the oracle.
+    The one line of __call__ that cannot run without a GPU is ``negative_prompt_attention_mask.to("cuda")`` (:1041): the
+    mask is handed in as a Tensor subclass whose ``.to("cuda")`` stays on the CPU.  Nothing of the reference is edited."""
+    print("G7/G11 LTXVideoPipeline.__call__, config 1")
+    import contextlib
+    ref_shims.install_pipeline_leaves()
+    import ltx_video.pipelines.pipeline_ltx_video as ref_pl
+
+    class _StaysOnCpu(torch.Tensor):
+        def to(self, *a, **k):
+            a = tuple(x for x in a if not (isinstance(x, str) and x.startswith("cuda")))
+            return torch.Tensor.to(self.as_subclass(torch.Tensor), *a, **k) if (a or k) else self.as_subclass(torch.Tensor)
+
+    # head_dim 64 / widths that are multiples of 64, so that the PRODUCT can run the same weights (tests/test_gpu_model.py)
+    cfg = dict(TINY_DIT, in_channels=128, out_channels=128, num_attention_heads=2, attention_head_dim=64,
+               cross_attention_dim=128, caption_channels=128)
+    model = build_dit(cfg, 95)
+    # diffusers' ConfigMixin.__getattr__ forwards config keys as attributes (``self.transformer.in_channels``, :1266);
+    # the shimmed ModelMixin does not, so the attribute is set here
+    model.in_channels = cfg["in_channels"]
+    draws = []
+
+    def logged_randn(shp, generator=None, device=None, dtype=None, layout=None):
+        n = ref_shims.randn_tensor(shp, generator=generator, device=device, dtype=dtype)
+        draws.append(n)
+        return n
+
+    ref_pl.randn_tensor = logged_randn
+    vae = ref_cva.CausalVideoAutoencoder.from_config(json.loads(json.dumps(jsonable(tiny_vae_b())))).eval()
+    pipe = object.__new__(ref_pl.LTXVideoPipeline)
+    pipe.transformer = model
+    pipe.vae = vae
+    pipe.patchifier = ref_sp.SymmetricPatchifier(patch_size=1)
+    pipe.scheduler = ref_rf.RectifiedFlowScheduler(sampler="Uniform", shifting="SD3", base_resolution=None,
+                                                   target_shift_terminal=0.1)
+    pipe.vae_scale_factor, pipe.video_scale_factor = 32, 8
+    pipe.allowed_inference_steps = None
+    pipe._execution_device = torch.device("cpu")
+
+    class _Bar:
+        def update(self, *a):
+            pass
+
+    pipe.progress_bar = lambda total=None: contextlib.nullcontext(_Bar())
+
+    rec = {}
+    calls = {"n": 0}
+    fwd = model.forward
+
+    def rec_forward(hidden_states, **kw):
+        i = calls["n"]
+        out = fwd(hidden_states, **kw)
+        rec[f"model_in.{i}"] = hidden_states.float()
+        rec[f"timestep.{i}"] = kw["timestep"].float()
+        rec[f"raw_pred.{i}"] = out[0].float()
+        if kw.get("skip_layer_mask") is not None:
+            rec[f"skip_layer_mask.{i}"] = kw["skip_layer_mask"].float()
+        calls["n"] += 1
+        return out
+
+    model.forward = rec_forward
+    den = ref_pl.LTXVideoPipeline.denoising_step
+    steps_seen = {"n": 0}
+
+    def rec_denoise(latents, noise_pred, current_timestep, conditioning_mask, t, extra_step_kwargs, **kw):
+        i = steps_seen["n"]
+        out = den(pipe, latents, noise_pred, current_timestep, conditioning_mask, t, extra_step_kwargs, **kw)
+        rec[f"guided.{i}"] = noise_pred.float()
+        rec[f"latents_in.{i}"] = latents.float()
+        rec[f"latents_out.{i}"] = out.float()
+        steps_seen["n"] += 1
+        return out
+
+    pipe.denoising_step = rec_denoise
+
+    g = torch.Generator().manual_seed(96)
+    T, cap = 12, cfg["caption_channels"]
+    pos, neg = torch.randn(1, T, cap, generator=g), torch.randn(1, T, cap, generator=g)
+    pmask, nmask = torch.ones(1, T), torch.ones(1, T)
+    pmask[:, 8:] = 0
+    nmask[:, 3:] = 0
+    kw = dict(height=256, width=256, num_frames=9, frame_rate=25.0, num_inference_steps=2, guidance_scale=3.0,
+              stg_scale=1.0, rescaling_scale=0.7, skip_block_list=[1], skip_layer_strategy=SkipLayerStrategy.AttentionValues)
+    out = pipe(prompt_embeds=pos, prompt_attention_mask=pmask, negative_prompt_embeds=neg,
+               negative_prompt_attention_mask=nmask.as_subclass(_StaysOnCpu), generator=torch.Generator().manual_seed(97),
+               output_type="latent", return_dict=False, is_video=True, vae_per_channel_normalize=True, joint_pass=True,
+               ltxv_model=types.SimpleNamespace(_interrupt=False), **kw)[0]
+    assert calls["n"] == 2 and steps_seen["n"] == 2 and len(draws) == 1
+    t = dict(rec)
+    t.update({f"w.{k}": v for k, v in model.state_dict().items()})
+    t["prompt_embeds"], t["negative_prompt_embeds"] = pos, neg
+    t["prompt_attention_mask"], t["negative_prompt_attention_mask"] = pmask, nmask
+    t["noise"] = draws[0]
+    t["timesteps"] = pipe.scheduler.timesteps.float()
+    t["out_latents"] = out.float()
+
+    # a second run with per-step guidance tables (the 13B multi-scale settings' form): lists + guidance_timesteps
+    calls["n"] = steps_seen["n"] = 0
+    rec.clear()
+    draws.clear()
+    kw2 = dict(kw, num_inference_steps=3, guidance_scale=[1.0, 3.0, 2.0], stg_scale=[0.0, 1.0, 0.5],
+               rescaling_scale=[1.0, 0.7, 0.9], guidance_timesteps=[1.0, 0.9, 0.3], skip_block_list=[[], [1], [0]])
+    out2 = pipe(prompt_embeds=pos, prompt_attention_mask=pmask, negative_prompt_embeds=neg,
+                negative_prompt_attention_mask=nmask.as_subclass(_StaysOnCpu), generator=torch.Generator().manual_seed(98),
+                output_type="latent", return_dict=False, is_video=True, vae_per_channel_normalize=True, joint_pass=True,
+                ltxv_model=types.SimpleNamespace(_interrupt=False), **kw2)[0]
+    assert calls["n"] == 3
+    t.update({f"tables.{k}": v for k, v in rec.items()})
+    t["tables.noise"] = draws[0]
+    t["tables.timesteps"] = pipe.scheduler.timesteps.float()
+    t["tables.out_latents"] = out2.float()
+    save("g7_pipeline_call", t, dict(cfg=cfg, kwargs={k: (v if not isinstance(v, SkipLayerStrategy) else v.name) for k, v in kw.items()},
+                                     tables_kwargs={k: (v if not isinstance(v, SkipLayerStrategy) else v.name) for k, v in kw2.items()},
+                                     T=T, grid=[2, 8, 8]))
+
+
+CASES = {"g7": g7, "g14": g14, "g13": g13, "g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
 
 
 def main():

@@ -67,7 +67,9 @@ def denoising_step(timesteps, latents, noise_pred, current_timestep, conditionin
 def guidance(noise_pred, num_conds, guidance_scale, stg_scale, rescaling_scale,
              do_cfg, do_stg, do_rescaling, cfg_star_rescale=True):
     """pipeline_ltx_video.py:1183-1222.  ``noise_pred`` is [num_conds*B, N, C] ordered
-    (uncond, text, text_perturbed) as built at :1035-1051."""
+    (uncond, text, text_perturbed) as built at :1035-1051.  Pinned by golden G7 (the reference's own __call__) at
+    B = 1; for B > 1 the reference's ``alpha * noise_pred_uncond`` ([B,1] x [B,N,C], :1199) does not broadcast per
+    sample -- the per-sample form below is this restatement's reading, identical at B = 1."""
     chunks = noise_pred.chunk(num_conds)
     if do_stg:
         text, perturb = chunks[-2:]

@@ -454,6 +454,29 @@ def test_latent_upsampler_and_bridge(dims, mid):
 
 
 # ------------------------------------------------------------------------ denoise loop
+def _oracle_loop(sd32, cfg, noise_tokens, emb, msk, tsch, grid, gs, stg, rs, skips, dtype):
+    """The oracle's restatement of the loop of LTXVideoPipeline.__call__ (:1104-1256), pinned to the reference's own
+    __call__ by tests/test_oracle_golden.py::test_g11_config1_loop; dtype bf16 = the reference's eager rendering."""
+    from oracle import dit, sched
+    f, h, w = grid
+    sd = {k: v.to(dtype) for k, v in sd32.items()}
+    pix = sched.latent_to_pixel_coords(sched.get_latent_coords(f, h, w, 1),
+                                       causal_fix=cfg.get("causal_temporal_positioning", False)).to(torch.float32)
+    pix[:, 0] = pix[:, 0] * (1.0 / 25.0)
+    fc = dit.precompute_freqs_cis(pix, cfg, dtype)
+    lat = noise_tokens.clone().float()
+    do_cfg, do_stg, do_rs = any(x > 1.0 for x in gs), any(x > 0.0 for x in stg), any(x != 1.0 for x in rs)
+    n = 1 + int(do_cfg) + int(do_stg)
+    for i, t in enumerate(tsch):
+        skip = dit.create_skip_layer_mask(cfg["num_layers"], 1, n, n - 1, skips[i], dtype)
+        npred = dit.transformer3d_forward(sd, cfg, torch.cat([lat.to(dtype)] * n), fc, emb.to(dtype), t.expand(n).unsqueeze(-1),
+                                          encoder_attention_mask=msk, latent_shape=(f, h, w), skip_layer_mask=skip,
+                                          skip_layer_strategy=dit.ATTENTION_VALUES)
+        v = sched.guidance(npred.float(), n, gs[i], stg[i], rs[i], do_cfg, do_stg, do_rs)
+        lat = sched.denoising_step(tsch, lat, v, t.expand(1).unsqueeze(-1), None, t)
+    return sched.unpatchify(lat, f, h, w)
+
+
 def test_pipeline_config1_two_steps():
     """BASELINE.json configs[0]: 256x256x9, 2 denoise steps -- the plumbing case.  Device loop
     (bf16 model, fp32 latents) against the oracle's fp32 loop on the same noise."""
@@ -475,18 +498,12 @@ def test_pipeline_config1_two_steps():
 
     # ---- oracle loop, fp32 (pipeline_ltx_video.py:1104-1256)
     tsch = sched.set_timesteps(steps, (1, 128, f, h, w))
-    fc = dit.precompute_freqs_cis(sched.fractional_coords(f, h, w, 1, 25.0), cfg, torch.float32)
-    skip = dit.create_skip_layer_mask(layers, 1, 3, 2, skip_blocks, torch.float32)
     emb = torch.cat([neg, pos, pos]).float()
     msk = torch.cat([nmask, pmask, pmask])
-    lat = lat0.clone()
-    for t in tsch:
-        npred = dit.transformer3d_forward(sd32, cfg, torch.cat([lat] * 3), fc, emb, t.expand(3).unsqueeze(-1),
-                                          encoder_attention_mask=msk, latent_shape=(f, h, w),
-                                          skip_layer_mask=skip, skip_layer_strategy=dit.ATTENTION_VALUES)
-        v = sched.guidance(npred, 3, gs, stg, rs, True, True, True)
-        lat = sched.denoising_step(tsch, lat, v, t.expand(1).unsqueeze(-1), None, t)
-    truth = sched.unpatchify(lat, f, h, w)
+    truth = _oracle_loop(sd32, cfg, lat0, emb, msk, tsch, (f, h, w), [gs] * steps, [stg] * steps, [rs] * steps,
+                         [skip_blocks] * steps, torch.float32)
+    eager = _oracle_loop(sd32, cfg, lat0, emb, msk, tsch, (f, h, w), [gs] * steps, [stg] * steps, [rs] * steps,
+                         [skip_blocks] * steps, BF)
 
     m = build_model(cfg, sd32)
     pipe = ltxmi.LTXVideoPipeline(m, ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1))
@@ -496,9 +513,40 @@ def test_pipeline_config1_two_steps():
                skip_block_list=skip_blocks, latents=lat0.to(DEV), output_type="latent")
     assert out.shape == truth.shape == (1, 128, f, h, w)
     torch.testing.assert_close(torch.tensor(pipe.scheduler.host_timesteps), tsch, rtol=1e-6, atol=1e-7)
-    e = rel(out, truth)
-    print(f"pipeline 2 steps: rel L2 {e:.3e}")
-    assert e < 1e-2
+    assert_parity(out, truth, eager, "pipeline config 1, 2 steps")
+
+
+@pytest.mark.parametrize("run", ["", "tables."])
+def test_pipeline_matches_the_references_own_call(golden, run):
+    """G11 on the PRODUCT: ltxmi.LTXVideoPipeline on the weights, prompts and noise draw of the reference's own
+    LTXVideoPipeline.__call__ run (tests/golden/g7_pipeline_call: config 1, 256x256x9, fp32 on the CPU) must land on the
+    reference's output latents -- within what the reference's bf16 eager path (the oracle loop in bf16) manages.
+    run "tables.": 3 steps with list-valued scales, guidance_timesteps and per-step skip lists (:959-1013)."""
+    import ltxmi
+    from oracle import pipeline_ctl as pc
+    t, meta = golden("g7_pipeline_call")
+    cfg = meta["cfg"]
+    kw = dict(meta["tables_kwargs" if run else "kwargs"])
+    f, h, w = meta["grid"]
+    sd32 = {k[2:]: v for k, v in t.items() if k.startswith("w.")}
+    truth = t[run + "out_latents"]
+    ts = t[run + "timesteps"]
+    emb = torch.cat([t["negative_prompt_embeds"], t["prompt_embeds"], t["prompt_embeds"]])
+    msk = torch.cat([t["negative_prompt_attention_mask"], t["prompt_attention_mask"], t["prompt_attention_mask"]])
+    gs, stg, rs, skips, _, _, _ = pc.guidance_tables(ts.tolist(), kw["guidance_scale"], kw["stg_scale"], kw["rescaling_scale"],
+                                                     kw["skip_block_list"], guidance_timesteps=kw.get("guidance_timesteps"))
+    eager = _oracle_loop(sd32, cfg, t[run + "noise"], emb, msk, ts, (f, h, w), gs, stg, rs, skips, BF)
+    m = build_model(cfg, sd32)
+    pipe = ltxmi.LTXVideoPipeline(m, ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1))
+    for k in ("skip_layer_strategy", "frame_rate"):
+        kw.pop(k, None)
+    out = pipe(prompt_embeds=t["prompt_embeds"].to(BF).to(DEV), prompt_attention_mask=t["prompt_attention_mask"].to(DEV),
+               negative_prompt_embeds=t["negative_prompt_embeds"].to(BF).to(DEV),
+               negative_prompt_attention_mask=t["negative_prompt_attention_mask"].to(DEV),
+               latents=t[run + "noise"].to(DEV), output_type="latent", frame_rate=25.0, **kw)
+    torch.testing.assert_close(torch.tensor(pipe.scheduler.host_timesteps), ts, rtol=1e-6, atol=1e-7)
+    assert out.shape == truth.shape
+    assert_parity(out, truth, eager, f"product pipeline vs the reference's own __call__ ({run or 'config 1'})")
 
 
 def test_prepare_conditioning_matches_oracle():

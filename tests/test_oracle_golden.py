@@ -318,8 +318,8 @@ def test_g14_pipeline_control(golden):
         torch.testing.assert_close(ts, t[f"ts.{i}"], rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(pc.prepare_latents(t["latents"], meta["t0"], t["noise.0"], shape), t["prepared"], **TOL)
     torch.testing.assert_close(pc.prepare_latents(None, 1.0, t["noise.1"], shape), t["prepared_none"], **TOL)
-    # the per-step guidance tables live inside __call__ (:959-1013, cannot run on CPU): parity unpinned,
-    # checked against the reference's documented behaviour on the shipped 13B-dev settings
+    # the per-step guidance tables (:959-1013) are pinned by test_g7_per_step_guidance_tables; here additionally the
+    # shipped 13B-dev settings
     gs, stg, rs, skips, do_cfg, do_stg, do_rs = pc.guidance_tables(
         [1.0, 0.99, 0.98, 0.93, 0.85, 0.5, 0.2], [1, 1, 6, 8, 6, 1, 1], [0, 0, 4, 4, 4, 2, 1], [1, 1, 0.5, 0.5, 1, 1, 1],
         [[], [11, 25, 35, 39], [22, 35, 39], [28], [28], [28], [28]],
@@ -327,3 +327,77 @@ def test_g14_pipeline_control(golden):
     # first table entry whose guidance timestep is <= t: mapping = [0, 3, 4, 5, 6, 6, 6]
     assert gs == [0.0, 8, 6, 0.0, 0.0, 0.0, 0.0] and stg == [0, 4, 4, 2, 1, 1, 1] and rs == [1, 0.5, 1, 1, 1, 1, 1]
     assert skips == [[], [28], [28], [28], [28], [28], [28]] and do_cfg and do_stg and do_rs
+
+
+def _g7_guided(raw, gs, stg, rs, do_cfg, do_stg, do_rs):
+    n = 1 + int(do_cfg) + int(do_stg)
+    return sched.guidance(raw, n, gs, stg, rs, do_cfg, do_stg, do_rs)
+
+
+def test_g7_guidance_math_as_run_by_the_reference_call(golden):
+    """G7: the guidance block of LTXVideoPipeline.__call__ (:1183-1222), captured from the reference's own __call__
+    (config 1: CFG 3 + STG 1 + std-rescale 0.7): what went into denoising_step, from what the transformer returned."""
+    t, meta = golden("g7_pipeline_call")
+    kw = meta["kwargs"]
+    for i in range(2):
+        out = _g7_guided(t[f"raw_pred.{i}"], kw["guidance_scale"], kw["stg_scale"], kw["rescaling_scale"], True, True, True)
+        torch.testing.assert_close(out, t[f"guided.{i}"], **TOL)
+        # the three conds were fed the same latents; timestep is the scheduler's, one row per cond
+        assert torch.equal(t[f"model_in.{i}"][0], t[f"model_in.{i}"][2])
+        torch.testing.assert_close(t[f"timestep.{i}"], t["timesteps"][i].expand(3).unsqueeze(-1), rtol=0, atol=0)
+
+
+def test_g7_per_step_guidance_tables(golden):
+    """The per-step tables of __call__ (:959-1013) with list-valued scales, guidance_timesteps and per-step skip lists:
+    the oracle's tables must reproduce what the reference fed its own loop (skip masks, and the guided prediction of
+    every step from that step's scales -- including the steps whose scales are zeroed)."""
+    from oracle import pipeline_ctl as pc
+    t, meta = golden("g7_pipeline_call")
+    kw = meta["tables_kwargs"]
+    ts = t["tables.timesteps"]
+    gs, stg, rs, skips, do_cfg, do_stg, do_rs = pc.guidance_tables(
+        ts.tolist(), kw["guidance_scale"], kw["stg_scale"], kw["rescaling_scale"], kw["skip_block_list"],
+        guidance_timesteps=kw["guidance_timesteps"])
+    assert do_cfg and do_stg and do_rs
+    cfg = meta["cfg"]
+    for i in range(len(ts)):
+        slm = dit.create_skip_layer_mask(cfg["num_layers"], 1, 3, 2, skips[i], torch.float32)
+        if f"tables.skip_layer_mask.{i}" in t:
+            torch.testing.assert_close(slm, t[f"tables.skip_layer_mask.{i}"], rtol=0, atol=0)
+        else:                                   # an empty skip list: the reference passes no mask at all (:171-175)
+            assert slm is None and skips[i] == []
+        out = _g7_guided(t[f"tables.raw_pred.{i}"], gs[i], stg[i], rs[i], do_cfg, do_stg, do_rs)
+        torch.testing.assert_close(out, t[f"tables.guided.{i}"], **TOL)
+
+
+def test_g11_config1_loop(golden):
+    """G11: config 1 end to end (256x256x9, 2 steps, fp32): the oracle's loop -- prepare_latents from the recorded
+    noise draw, model, guidance, Euler step, unpatchify -- against the reference's own __call__."""
+    from oracle import pipeline_ctl as pc
+    t, meta = golden("g7_pipeline_call")
+    cfg, kw = meta["cfg"], meta["kwargs"]
+    f, h, w = meta["grid"]
+    sd = sub(t, "w.")
+    shape = (1, cfg["in_channels"], f, h, w)
+    ts = pc.retrieve_timesteps(kw["num_inference_steps"], shape)
+    torch.testing.assert_close(ts, t["timesteps"], rtol=1e-6, atol=1e-7)
+    lat, _ = sched.patchify(pc.prepare_latents(None, 1.0, t["noise"], shape))
+    torch.testing.assert_close(lat, t["latents_in.0"], **TOL)
+    # the model config of this run has no `causal_temporal_positioning` (default False, as for the 2B 0.9.0 config):
+    # prepare_conditioning then builds the pixel coordinates WITHOUT the causal fix (:1530-1538)
+    pix = sched.latent_to_pixel_coords(sched.get_latent_coords(f, h, w, 1),
+                                       causal_fix=cfg.get("causal_temporal_positioning", False)).to(torch.float32)
+    pix[:, 0] = pix[:, 0] * (1.0 / kw["frame_rate"])
+    fc = dit.precompute_freqs_cis(pix, cfg, torch.float32)
+    emb = torch.cat([t["negative_prompt_embeds"], t["prompt_embeds"], t["prompt_embeds"]])
+    msk = torch.cat([t["negative_prompt_attention_mask"], t["prompt_attention_mask"], t["prompt_attention_mask"]])
+    skip = dit.create_skip_layer_mask(cfg["num_layers"], 1, 3, 2, kw["skip_block_list"], torch.float32)
+    for i, tt in enumerate(ts):
+        raw = dit.transformer3d_forward(sd, cfg, torch.cat([lat] * 3), fc, emb, tt.expand(3).unsqueeze(-1),
+                                        encoder_attention_mask=msk, latent_shape=(f, h, w), skip_layer_mask=skip,
+                                        skip_layer_strategy=dit.ATTENTION_VALUES)
+        torch.testing.assert_close(raw, t[f"raw_pred.{i}"], rtol=2e-5, atol=5e-6)
+        v = _g7_guided(raw, kw["guidance_scale"], kw["stg_scale"], kw["rescaling_scale"], True, True, True)
+        lat = sched.denoising_step(ts, lat, v, tt.expand(1).unsqueeze(-1), None, tt)
+        torch.testing.assert_close(lat, t[f"latents_out.{i}"], rtol=2e-5, atol=5e-6)
+    torch.testing.assert_close(sched.unpatchify(lat, f, h, w), t["out_latents"], rtol=2e-5, atol=5e-6)
