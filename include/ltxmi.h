@@ -76,6 +76,12 @@ typedef struct ltxmi_gemm_args {
     int32_t     rows_per_group;       /* tokens sharing one modulation row (N_tok / T1)     */
     int32_t     algo;                 /* 0 = kernel chosen by shape (the product setting); diagnostics:
                                          128 = 128x128-tile kernel, 256 = non-persistent 256x256 kernel */
+    /* Optional (plain epilogue only): for the output columns < rowsumsq_cols the epilogue also writes
+     * rowsumsq[m * rowsumsq_ld + n / 64] = sum over that 64-column block of (bf16 C[m, n])^2 as fp32.
+     * The fused QKV projection asks for it over the q columns: the attention kernel then applies q's
+     * RMSNorm (over ALL heads, attention.py:478-479,1040-1041) + RoPE (:960-975,1053-1055) while it loads Q,
+     * so q needs no pass of its own between the projection and attention.  NULL = off. */
+    float*      rowsumsq; int32_t rowsumsq_cols; int64_t rowsumsq_ld;
 } ltxmi_gemm_args;
 
 int ltxmi_gemm_bf16(const ltxmi_gemm_args* args, void* stream);
@@ -128,9 +134,21 @@ typedef struct ltxmi_attn_args {
     const float* key_bias; int64_t bias_stride_b;   /* NULL = no bias */
     int32_t B, H, Lq, Lk, head_dim;
     float   softmax_scale;
+    /* Optional fused q_norm + RoPE on load (the "fused QKV-projection + RoPE" of the path, attention.py:1040-1055):
+     * q is the RAW projection output; q_rowsumsq[b * stride_b + l * stride_l + j], j < q_rowsumsq_blocks = H*head_dim/64,
+     * are the projection GEMM's per-64-column sums of squares of that row (ltxmi_gemm_args.rowsumsq).  The kernel
+     * applies x * rsqrt(mean(x^2) + q_norm_eps) * q_norm_weight[c] and, if rope_cos/rope_sin are given, the
+     * interleaved-pair rotation with table row b * rope_stride_b + l * rope_stride_l (strides in elements; stride_b = 0:
+     * one table shared by the batch) while it loads Q.  Only where ltxmi_attention_fuses_qnorm() says 1; NULL = off. */
+    const float* q_rowsumsq; int64_t q_rowsumsq_stride_b, q_rowsumsq_stride_l; int32_t q_rowsumsq_blocks;
+    const void*  q_norm_weight; float q_norm_eps;
+    const void*  rope_cos; const void* rope_sin; int64_t rope_stride_b, rope_stride_l;
 } ltxmi_attn_args;
 
 int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* args, void* stream);
+/* 1 if ltxmi_attention_fwd_bf16 can normalise + rotate q on load for this shape (large head_dim-64 self-attention
+ * without a key bias), else 0: the caller then runs ltxmi_rmsnorm_rope_bf16 on q as a pass of its own. */
+int ltxmi_attention_fuses_qnorm(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias);
 
 /* ---------------------------------------------------------------------------------
  * Small elementwise helpers on the DiT path.

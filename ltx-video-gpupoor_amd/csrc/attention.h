@@ -13,10 +13,17 @@ struct AttnParams {
     int B, H, Lq, Lk;
     float scale_log2e;   // softmax_scale * log2(e)
     int q_tiles;         // query tiles per (batch, head)
+    // optional: q arrives as the raw projection output; RMSNorm over all H * dh channels (row sums of squares
+    // given as per-64-column partials by the projection GEMM) x weight, then interleaved RoPE, applied on load
+    const float* q_ss; int64_t q_ss_sb, q_ss_sl; int q_ss_n;
+    const uint16_t* q_w; float q_eps;
+    const uint16_t* rope_cos; const uint16_t* rope_sin; int64_t rope_sb, rope_sl;
 };
 
 // attention_pipe.hip: software-pipelined self-attention (head_dim 64, no key bias).
 // Returns -1 when the shape is not taken (the caller then uses attention.hip's kernel).
 int launch_attn_pipe(AttnParams p, hipStream_t stream);
+// whether launch_attn_pipe takes this shape (the only kernel that can normalise q on load)
+bool attn_pipe_takes(int B, int H, int Lq, int Lk, int head_dim, bool has_bias);
 
 }  // namespace ltxmi

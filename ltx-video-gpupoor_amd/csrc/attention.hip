@@ -504,21 +504,44 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk;
     p.scale_log2e = a->softmax_scale * LOG2E;
     p.q_tiles = (a->Lq + Q_PER_WG - 1) / Q_PER_WG;
+    p.q_ss = a->q_rowsumsq; p.q_ss_sb = a->q_rowsumsq_stride_b; p.q_ss_sl = a->q_rowsumsq_stride_l;
+    p.q_ss_n = a->q_rowsumsq_blocks;
+    p.q_w = (const uint16_t*)a->q_norm_weight; p.q_eps = a->q_norm_eps;
+    p.rope_cos = (const uint16_t*)a->rope_cos; p.rope_sin = (const uint16_t*)a->rope_sin;
+    p.rope_sb = a->rope_stride_b; p.rope_sl = a->rope_stride_l;
+    const bool pipe_ok = LTXMI_ATTN_PIPE && attn_pipe_takes(a->B, a->H, a->Lq, a->Lk, a->head_dim, a->key_bias != nullptr);
+    if (a->q_rowsumsq) {
+        LTXMI_REQUIRE(pipe_ok, LTXMI_ERR_UNSUPPORTED,
+                      "ltxmi_attention_fwd_bf16: q normalisation on load is not available for this shape "
+                      "(ask ltxmi_attention_fuses_qnorm first)");
+        LTXMI_REQUIRE(a->q_norm_weight && a->q_rowsumsq_blocks == a->H * a->head_dim / 64 &&
+                          (((uintptr_t)a->q_rowsumsq) & 3) == 0 && (((uintptr_t)a->q_norm_weight) & 15) == 0,
+                      LTXMI_ERR_INVALID_ARG, "ltxmi_attention_fwd_bf16: bad q_rowsumsq / q_norm_weight geometry");
+        LTXMI_REQUIRE((a->rope_cos == nullptr) == (a->rope_sin == nullptr), LTXMI_ERR_INVALID_ARG,
+                      "ltxmi_attention_fwd_bf16: rope_cos and rope_sin must both be given or both be NULL");
+        if (a->rope_cos)
+            LTXMI_REQUIRE((((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin) & 15) == 0 && a->rope_stride_l % 8 == 0 &&
+                              a->rope_stride_b % 8 == 0,
+                          LTXMI_ERR_INVALID_ARG, "ltxmi_attention_fwd_bf16: RoPE tables must be 16-byte aligned rows");
+    }
     hipStream_t s = (hipStream_t)stream;
     // 64 query rows per wave (two blocks sharing each K/V fragment) once there is enough work to
     // fill the chip with 256-row workgroups; 32 rows per wave otherwise (and always at head_dim 128,
     // where two blocks of accumulators do not fit the register file at 2 waves per SIMD)
     const int64_t wg256 = (int64_t)a->B * a->H * ((a->Lq + 255) / 256);
     if (a->head_dim == 64) {
-#if LTXMI_ATTN_PIPE
         // large self-attention: the software-pipelined LDS-DMA kernel (attention_pipe.hip)
-        if (wg256 >= 512 && !a->key_bias) {
+        if (pipe_ok) {
             const int rc = launch_attn_pipe(p, s);
             if (rc != -1) return rc;
+            LTXMI_REQUIRE(!a->q_rowsumsq, LTXMI_ERR_UNSUPPORTED, "ltxmi_attention_fwd_bf16: tensor too large for q normalisation on load");
         }
-#endif
         if (wg256 >= 512 && !a->key_bias) return launch<64, false, ATTN_QB_BIG>(p, s);
         return a->key_bias ? launch<64, true, 1>(p, s) : launch<64, false, 1>(p, s);
     }
     return a->key_bias ? launch<128, true, 1>(p, s) : launch<128, false, 1>(p, s);
+}
+
+extern "C" int ltxmi_attention_fuses_qnorm(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias) {
+    return (LTXMI_ATTN_PIPE && attn_pipe_takes(B, H, Lq, Lk, head_dim, has_key_bias != 0)) ? 1 : 0;
 }

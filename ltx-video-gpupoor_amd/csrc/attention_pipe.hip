@@ -277,6 +277,37 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
         const int q_ld = row < p.Lq ? row : p.Lq - 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) X.q[s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * L.hh);
+        if (p.q_ss) {
+            // fused K1: q is the raw projection output.  q_norm (RMSNorm over all H * dh channels, attention.py:478-479,
+            // 1040-1041) from the projection GEMM's partial sums of squares, x weight, then the interleaved-pair RoPE on
+            // the flat channel axis (:960-975, 1053-1055) -- the arithmetic of rmsnorm_rope_kernel (rowops.hip), one
+            // rounding to bf16 at the end.
+            const float* ss = p.q_ss + (int64_t)b * p.q_ss_sb + (int64_t)q_ld * p.q_ss_sl;
+            float s2 = 0.f;
+            for (int j = 0; j < p.q_ss_n; ++j) s2 += ss[j];
+            const float rstd = rsqrtf(s2 / (float)(p.H * DH) + p.q_eps);
+            const int64_t trow = (int64_t)b * p.rope_sb + (int64_t)q_ld * p.rope_sl;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int col = head * DH + 16 * s + 8 * L.hh;
+                const bf16x8 wv = *(const bf16x8*)(p.q_w + col);
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (float)X.q[s][e] * rstd * (float)wv[e];
+                if (p.rope_cos) {
+                    const bf16x8 cv = *(const bf16x8*)(p.rope_cos + trow + col), sv = *(const bf16x8*)(p.rope_sin + trow + col);
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float r0 = o[e] * (float)cv[e] - o[e + 1] * (float)sv[e];
+                        const float r1 = o[e + 1] * (float)cv[e + 1] + o[e] * (float)sv[e + 1];
+                        o[e] = r0;
+                        o[e + 1] = r1;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) X.q[s][e] = (__bf16)o[e];
+            }
+        }
         X.m = -INFINITY;
         X.l = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -407,6 +438,11 @@ extern "C" int ltxmi_debug_set_attn_stamps(void* buf) {
 #ifndef LTXMI_ATTN_PIPE_OCC
 #define LTXMI_ATTN_PIPE_OCC 2
 #endif
+
+bool attn_pipe_takes(int B, int H, int Lq, int Lk, int head_dim, bool has_bias) {
+    // enough 256-row query tiles to fill the chip with two workgroups per CU
+    return head_dim == 64 && !has_bias && (int64_t)B * H * ((Lq + 255) / 256) >= 512 && Lk > 0;
+}
 
 int launch_attn_pipe(AttnParams p, hipStream_t stream) {
     // the buffer descriptors address a (batch, head)'s K / V rows with 32-bit byte offsets

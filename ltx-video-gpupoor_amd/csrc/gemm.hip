@@ -52,10 +52,15 @@ struct GemmParams {
     int pad_replicate;   // spatial padding mode
     // depth-to-space epilogue (EPI == EPI_D2S)
     const uint16_t* res; int res_ch;
+    // EPI_SUMSQ: fp32 [M, sumsq_ld] partial row sums of squares of the bf16 outputs, one per 64-column block
+    float* sumsq; int sumsq_cols; int64_t sumsq_ld;
 };
 
 constexpr int EPI_D2S = 4;   // internal: conv + pixel-shuffle(2,2,2) scatter (+ residual)
 constexpr int EPI_RESIDUAL = 5;   // internal: GATE_RESIDUAL without a gate (C = R + acc + bias)
+constexpr int EPI_SUMSQ = 6;      // internal: plain store + per-(row, 64-column block) sum of squares of the stored bf16
+                                  // values for the columns < sumsq_cols (the q part of a fused QKV projection: the
+                                  // attention kernel turns them into q's RMSNorm factor, attention.py:1040-1041)
 
 // 64 zero bytes: LDS-DMA source for zero-padded taps
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[16];
@@ -278,6 +283,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
         const bool m_ok = m < p.M;
         const int mc = m_ok ? m : p.M - 1;
         const uint16_t* gate_row = GATED ? p.gate_temb + (int64_t)(mc / p.rows_per_group) * p.gate_ld : nullptr;
+        float ss[NI / 4 > 0 ? NI / 4 : 1];                       // EPI_SUMSQ: one partial per 64 columns (4 fragments)
+#pragma unroll
+        for (int q = 0; q < (NI / 4 > 0 ? NI / 4 : 1); ++q) ss[q] = 0.f;
         u32x2 ge_v[NI], rr_v[NI];
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -334,6 +342,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
             o[0] = pack_bf16(v[0], v[1]);
             o[1] = pack_bf16(v[2], v[3]);
             *(u32x2*)(p.C + (int64_t)m * p.ldc + n) = o;
+            if (EPI == EPI_SUMSQ)
+                ss[j / 4] += bf_lo(o[0]) * bf_lo(o[0]) + bf_hi(o[0]) * bf_hi(o[0]) + bf_lo(o[1]) * bf_lo(o[1]) + bf_hi(o[1]) * bf_hi(o[1]);
+        }
+        if (EPI == EPI_SUMSQ) {
+            static_assert(EPI != EPI_SUMSQ || NI % 4 == 0, "sum-of-squares partials are per 64 columns");
+#pragma unroll
+            for (int q = 0; q < NI / 4; ++q) {
+                float s = ss[q];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                const int nb = n0 + wn * WN + q * 64;            // first column of this 64-column block
+                if (lane < 16 && m_ok && nb < p.sumsq_cols) p.sumsq[(int64_t)m * p.sumsq_ld + (nb >> 6)] = s;
+            }
         }
     }
 }
@@ -363,7 +384,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int A_INSTR = (BM / 8) / NW;
     constexpr int B_INSTR = (BN / 8) / NW;
-    constexpr int N_STORES = (MI / 2) * 4;       // 16-byte buffer stores per wave and tile
+    constexpr int N_STORES = (MI / 2) * 4 + (EPI == EPI_SUMSQ ? MI : 0);   // buffer stores per wave and tile
     static_assert(MI % 2 == 0 && WN == 64, "epilogue scratch is a 32 x 64 bf16 chunk per wave");
     static_assert(N_STORES <= 63, "vmcnt immediate is 6 bits");
 
@@ -450,6 +471,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     const uint32_t c_bytes = (uint32_t)(((int64_t)(p.M - 1) * p.ldc + p.N) * 2);
     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, c_bytes, 0x00020000);
     const int erow = lane & 15, ecol = (lane >> 4) * 4;
+    // EPI_SUMSQ: the partial sums leave through a descriptor too (their count per tile must be a constant)
+    const __amdgpu_buffer_rsrc_t ss_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.sumsq, 0, EPI == EPI_SUMSQ ? (uint32_t)(((int64_t)(p.M - 1) * p.sumsq_ld + (p.sumsq_cols >> 6)) * 4) : 0u, 0x00020000);
 
     f32x4 acc[MI][NI];
     bf16x8 af0[MI], bf0[NI], af1[MI], bf1[NI];
@@ -488,6 +512,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
                     if (RESID) rr_v[j] = *(const u32x2*)(p.R + (int64_t)mc * p.ldr + ncl[j]);
                 }
                 const int row_l = ii * 16 + erow;
+                float ss = 0.f;
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
@@ -513,9 +538,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
                     u32x2 o;
                     o[0] = pack_bf16(v[0], v[1]);
                     o[1] = pack_bf16(v[2], v[3]);
+                    if (EPI == EPI_SUMSQ)
+                        ss += bf_lo(o[0]) * bf_lo(o[0]) + bf_hi(o[0]) * bf_hi(o[0]) + bf_lo(o[1]) * bf_lo(o[1]) + bf_hi(o[1]) * bf_hi(o[1]);
                     // 8-byte piece (j*4 + lane>>4) of scratch row row_l; 16-byte chunks XOR-swizzled by row
                     const int chunk = j * 2 + (lane >> 5);
                     *(u32x2*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4) + ((lane >> 4) & 1) * 8) = o;
+                }
+                if (EPI == EPI_SUMSQ) {
+                    // this wave's 64 columns of row m: lanes l, l+16, l+32, l+48 hold its four 16-column pieces
+                    ss += __shfl_xor(ss, 16, 64);
+                    ss += __shfl_xor(ss, 32, 64);
+                    const int nb = n0 + wn * WN;
+                    const uint32_t off = (lane < 16 && m < p.M && nb < p.sumsq_cols)
+                                             ? (uint32_t)(((int64_t)m * p.sumsq_ld + (nb >> 6)) * 4) : 0xfffffff0u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ss), ss_rsrc, off, 0, 0);
                 }
             }
             // read the 32 x 64 chunk back row-major: lane -> (row l>>3 [+8t], 16-byte chunk l&7)
@@ -706,6 +742,7 @@ static int launch_tile(const GemmParams& p0, int epi, hipStream_t stream, const 
     if constexpr (MODE == 0) {
         switch (epi) {
             case LTXMI_EPI_NONE: LTXMI_GEMM_LAUNCH(LTXMI_EPI_NONE) break;
+            case EPI_SUMSQ: LTXMI_GEMM_LAUNCH(EPI_SUMSQ) break;
             case LTXMI_EPI_GELU_TANH: LTXMI_GEMM_LAUNCH(LTXMI_EPI_GELU_TANH) break;
             case LTXMI_EPI_SILU: LTXMI_GEMM_LAUNCH(LTXMI_EPI_SILU) break;
             case LTXMI_EPI_GATE_RESIDUAL: LTXMI_GEMM_LAUNCH(LTXMI_EPI_GATE_RESIDUAL) break;
@@ -741,6 +778,7 @@ static int launch_persistent(const GemmParams& p0, int epi, hipStream_t stream, 
     }
     switch (epi) {
         case LTXMI_EPI_NONE: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_NONE) break;
+        case EPI_SUMSQ: LTXMI_GEMM_LAUNCH_P(EPI_SUMSQ) break;
         case LTXMI_EPI_GELU_TANH: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_GELU_TANH) break;
         case LTXMI_EPI_SILU: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_SILU) break;
         case LTXMI_EPI_GATE_RESIDUAL: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_GATE_RESIDUAL) break;
@@ -800,8 +838,18 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
     p.tiles_m = p.tiles_n = 0;
     p.cB = p.cT = p.cH = p.cW = p.cCin = 1; p.oT = p.oH = p.oW = 1; p.sT = p.sHW = 1; p.tpad = 0; p.tzero = 0; p.pad_replicate = 0; p.res = nullptr; p.res_ch = 0;
+    p.sumsq = a->rowsumsq; p.sumsq_cols = a->rowsumsq_cols; p.sumsq_ld = a->rowsumsq_ld;
+    if (a->rowsumsq) {
+        LTXMI_REQUIRE(a->epilogue == LTXMI_EPI_NONE, LTXMI_ERR_UNSUPPORTED, "ltxmi_gemm_bf16: rowsumsq needs the plain epilogue");
+        LTXMI_REQUIRE(a->rowsumsq_cols > 0 && a->rowsumsq_cols % 64 == 0 && a->rowsumsq_cols <= a->N &&
+                          a->rowsumsq_ld >= a->rowsumsq_cols / 64 && (((uintptr_t)a->rowsumsq) & 3) == 0,
+                      LTXMI_ERR_INVALID_ARG, "ltxmi_gemm_bf16: rowsumsq_cols=%d must be a multiple of 64 within N, ld >= cols/64",
+                      a->rowsumsq_cols);
+        LTXMI_REQUIRE((int64_t)a->M * a->rowsumsq_ld * 4 < (1ll << 32), LTXMI_ERR_UNSUPPORTED, "ltxmi_gemm_bf16: rowsumsq too large");
+    }
     hipStream_t s = (hipStream_t)stream;
-    const int epi = (a->epilogue == LTXMI_EPI_GATE_RESIDUAL && !a->gate_table) ? EPI_RESIDUAL : a->epilogue;
+    const int epi = a->rowsumsq ? EPI_SUMSQ
+                                : ((a->epilogue == LTXMI_EPI_GATE_RESIDUAL && !a->gate_table) ? EPI_RESIDUAL : a->epilogue);
     // Tile choice: 256x256 (8 waves) when it still fills the 256 CUs, else 128x128 (4 waves,
     // 2 blocks/CU); skinny problems (adaLN tables, text K/V) take the 128x128 path too.
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
@@ -869,6 +917,7 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
     p.C = (uint16_t*)a->y; p.ldc = a->Cout;
     p.M = (int)M; p.N = a->Cout; p.K = 9 * kt * a->Cin;
     p.R = nullptr; p.ldr = 0; p.gate_table = nullptr; p.gate_temb = nullptr; p.gate_ld = 0; p.rows_per_group = 1;
+    p.sumsq = nullptr; p.sumsq_cols = 0; p.sumsq_ld = 0;
     p.tiles_m = p.tiles_n = 0;
     p.cB = a->B; p.cT = a->T; p.cH = a->H; p.cW = a->W; p.cCin = a->Cin;
     p.oT = oT; p.oH = oH; p.oW = oW; p.sT = sT; p.sHW = sHW;

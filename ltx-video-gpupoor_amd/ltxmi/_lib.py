@@ -17,7 +17,8 @@ class GemmArgs(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("lda", c_int64), ("W", c_void_p), ("ldw", c_int64), ("bias", c_void_p),
                 ("C", c_void_p), ("ldc", c_int64), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("epilogue", c_int), ("residual", c_void_p), ("ldr", c_int64), ("gate_table", c_void_p),
-                ("gate_temb", c_void_p), ("gate_ld", c_int64), ("rows_per_group", c_int), ("algo", c_int)]
+                ("gate_temb", c_void_p), ("gate_ld", c_int64), ("rows_per_group", c_int), ("algo", c_int),
+                ("rowsumsq", c_void_p), ("rowsumsq_cols", c_int), ("rowsumsq_ld", c_int64)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -27,7 +28,10 @@ class AttnArgs(ctypes.Structure):
                 ("o", c_void_p), ("o_stride_b", c_int64), ("o_stride_l", c_int64),
                 ("key_bias", c_void_p), ("bias_stride_b", c_int64),
                 ("B", c_int), ("H", c_int), ("Lq", c_int), ("Lk", c_int), ("head_dim", c_int),
-                ("softmax_scale", c_float)]
+                ("softmax_scale", c_float),
+                ("q_rowsumsq", c_void_p), ("q_rowsumsq_stride_b", c_int64), ("q_rowsumsq_stride_l", c_int64),
+                ("q_rowsumsq_blocks", c_int), ("q_norm_weight", c_void_p), ("q_norm_eps", c_float),
+                ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("rope_stride_b", c_int64), ("rope_stride_l", c_int64)]
 
 
 class Conv3dArgs(ctypes.Structure):
@@ -50,6 +54,7 @@ SIGNATURES = {
     "ltxmi_rmsnorm_rope_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p,
                                         c_int64, c_int, c_void_p]),
     "ltxmi_attention_fwd_bf16": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
+    "ltxmi_attention_fuses_qnorm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "ltxmi_silu_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ltxmi_timestep_embedding_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ltxmi_stg_blend_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p]),

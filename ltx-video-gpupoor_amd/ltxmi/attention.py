@@ -211,8 +211,14 @@ class AttnProcessor2_0:
         if not isinstance(attn.q_norm, RMSNorm):
             raise NotImplementedError("ltxmi.AttnProcessor2_0: qk_norm=None is not on this path")
 
+        q_fused = None                      # (row sums of squares, weight, eps), (cos, sin, period): q finished on load
         if not is_cross:
-            qkv = ops.gemm(x2, wqkv, bqkv)                                         # [B*N, 3D]
+            # K1, the fused QKV projection + q/k RMSNorm + RoPE (attention.py:1040-1059).  Where the attention kernel can
+            # finish q while it loads it, the projection GEMM also emits q's per-row sums of squares and q gets NO pass of
+            # its own: the only launch between the projection and attention is k's norm + RoPE.
+            fuse_q = ops.attention_fuses_qnorm(B, H, N, N, dh) and D % 64 == 0 and attention_mask is None
+            ss = torch.empty((B * N, D // 64), dtype=torch.float32, device=x2.device) if fuse_q else None
+            qkv = ops.gemm(x2, wqkv, bqkv, rowsumsq=ss, rowsumsq_cols=D if fuse_q else 0)   # [B*N, 3D]
             q2, k2, v2 = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
             cos = sin = None
             period = 0
@@ -223,7 +229,10 @@ class AttnProcessor2_0:
                 cos2, sin2 = cos.reshape(-1, D), sin.reshape(-1, D)
                 period = cos2.shape[0]                  # N (shared) or B*N (per sample)
                 cos, sin = cos2, sin2
-            ops.rmsnorm_rope_(q2, attn.q_norm.weight, attn.q_norm.eps, cos, sin, period)
+            if fuse_q:
+                q_fused = ((ss, attn.q_norm.weight, attn.q_norm.eps), (cos, sin, period) if cos is not None else None)
+            else:
+                ops.rmsnorm_rope_(q2, attn.q_norm.weight, attn.q_norm.eps, cos, sin, period)
             ops.rmsnorm_rope_(k2, attn.k_norm.weight, attn.k_norm.eps, cos, sin, period)
             Lk = N
             q4 = qkv.view(B, N, 3, H, dh)[:, :, 0]
@@ -270,7 +279,8 @@ class AttnProcessor2_0:
                 if attention_mask.dim() != 3 or attention_mask.shape[1] != 1:
                     raise NotImplementedError("ltxmi.AttnProcessor2_0: attention_mask must be a [B,1,Lk] bias")
                 mask4 = attention_mask.reshape(B, 1, 1, Lk)
-            a4 = pay_attention([q4, k4, v4], attention_mask=mask4, softmax_scale=attn.scale)   # [B,N,H,dh]
+            a4 = pay_attention([q4, k4, v4], attention_mask=mask4, softmax_scale=attn.scale,
+                               q_norm=q_fused[0] if q_fused else None, rope=q_fused[1] if q_fused else None)   # [B,N,H,dh]
             a3 = a4.view(B, N, D)
             if host_mask is not None and any(m != 1.0 for m in host_mask):
                 m_dev = skip_layer_mask.reshape(B).to(torch.float32)

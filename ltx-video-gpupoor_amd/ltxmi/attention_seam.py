@@ -42,7 +42,9 @@ _BIAS_CACHE = None
 @torch.compiler.disable()
 def pay_attention(qkv_list, dropout_p=0., softmax_scale=None, causal=False, window_size=(-1, -1),
                   deterministic=False, version=None, force_attention=None, attention_mask=None,
-                  cross_attn=False, q_lens=None, k_lens=None):
+                  cross_attn=False, q_lens=None, k_lens=None, q_norm=None, rope=None):
+    """``q_norm`` / ``rope`` (extension, used by AttnProcessor2_0 only): q is the raw projection output and is
+    RMS-normalised (+ rotated) by the kernel while it loads it -- see ops.attention."""
     q, k, v = qkv_list
     qkv_list.clear()
     if causal or tuple(window_size) != (-1, -1) or dropout_p != 0.:
@@ -86,7 +88,9 @@ def pay_attention(qkv_list, dropout_p=0., softmax_scale=None, causal=False, wind
         q, k, v = q[:, :szq], k[:, :szk], v[:, :szk]
 
     bias = None if attention_mask is None else _key_bias_from_mask(attention_mask, b, k.size(1))
-    x = ops.attention(q, k, v, key_bias=bias, softmax_scale=softmax_scale)
+    if q_norm is not None and (q_lens is not None or k_lens is not None):
+        raise NotImplementedError("pay_attention: q_norm on load with q_lens / k_lens")
+    x = ops.attention(q, k, v, key_bias=bias, softmax_scale=softmax_scale, q_norm=q_norm, rope=rope)
     x = x.type(out_dtype)
     if final_padding > 0:
         x = torch.cat([x, torch.empty((x.shape[0], final_padding, *x.shape[-2:]), dtype=x.dtype, device=x.device)], 1)

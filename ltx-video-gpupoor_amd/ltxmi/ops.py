@@ -77,7 +77,7 @@ def _rows(t):
 
 
 def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, gate_table=None, gate_temb=None,
-         rows_per_group=1, algo=0):
+         rows_per_group=1, algo=0, rowsumsq=None, rowsumsq_cols=0):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  ``a``/``out``/``residual`` may be row-strided 2-D views.
     gate_temb: 2-D view [groups, N] (row stride = gate_ld)."""
     _chk_bf16(a, w, bias, out, residual, gate_table, gate_temb)
@@ -106,6 +106,12 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, gate_table
         args.gate_ld = gate_temb.stride(0) if gate_temb.dim() == 2 else 0
     args.rows_per_group = rows_per_group
     args.algo = algo               # 0 = kernel chosen by shape; 128 / 256: diagnostics (include/ltxmi.h)
+    if rowsumsq is not None:
+        # fp32 [M, rowsumsq_cols/64]: per-64-column sums of squares of the bf16 outputs, columns < rowsumsq_cols
+        if rowsumsq.dtype != torch.float32 or rowsumsq.dim() != 2 or rowsumsq.shape[0] != M or rowsumsq.stride(1) != 1 \
+                or rowsumsq.shape[1] * 64 < rowsumsq_cols:
+            raise ValueError("ltxmi.gemm: rowsumsq must be fp32 [M, >= rowsumsq_cols/64]")
+        args.rowsumsq, args.rowsumsq_cols, args.rowsumsq_ld = rowsumsq.data_ptr(), rowsumsq_cols, rowsumsq.stride(0)
     tok = _prof_begin(("gemm", M, N, K, epilogue))
     check(lib.ltxmi_gemm_bf16(ctypes.byref(args), _stream()), "ltxmi_gemm_bf16")
     _prof_end(tok)
@@ -145,9 +151,17 @@ def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, rope_period=0):
     return x
 
 
-def attention(q, k, v, out=None, key_bias=None, softmax_scale=None):
+def attention_fuses_qnorm(B, H, Lq, Lk, dh, has_key_bias=False):
+    """Whether ``attention(..., q_norm=...)`` is available for this shape (large head_dim-64 self-attention)."""
+    return bool(lib.ltxmi_attention_fuses_qnorm(B, H, Lq, Lk, dh, int(has_key_bias)))
+
+
+def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None, rope=None):
     """q [B,Lq,H,dh], k/v [B,Lk,H,dh] (NHD; batch and token strides free, (H,dh) contiguous).
-    key_bias: fp32 [B,Lk] additive (broadcast over heads and queries)."""
+    key_bias: fp32 [B,Lk] additive (broadcast over heads and queries).
+    q_norm = (rowsumsq fp32 [B*Lq, H*dh/64] from ``gemm(..., rowsumsq=)``, weight bf16 [H*dh], eps): q is the raw
+    projection output and is RMS-normalised over all heads (+ rotated with rope = (cos [period, H*dh], sin, period))
+    while the kernel loads it -- only where ``attention_fuses_qnorm`` says so."""
     _chk_bf16(q, k, v, out)
     B, Lq, H, dh = q.shape
     Lk = k.shape[1]
@@ -167,6 +181,24 @@ def attention(q, k, v, out=None, key_bias=None, softmax_scale=None):
         a.key_bias, a.bias_stride_b = key_bias.data_ptr(), key_bias.stride(0)
     a.B, a.H, a.Lq, a.Lk, a.head_dim = B, H, Lq, Lk, dh
     a.softmax_scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(dh)
+    if q_norm is not None:
+        ss, w, eps = q_norm
+        nb = H * dh // 64
+        if ss.dtype != torch.float32 or ss.dim() != 2 or ss.shape != (B * Lq, nb) or ss.stride(1) != 1:
+            raise ValueError("ltxmi.attention: q_norm row sums must be fp32 [B*Lq, H*dh/64]")
+        _chk_bf16(w)
+        a.q_rowsumsq, a.q_rowsumsq_stride_b, a.q_rowsumsq_stride_l = ss.data_ptr(), Lq * ss.stride(0), ss.stride(0)
+        a.q_rowsumsq_blocks, a.q_norm_weight, a.q_norm_eps = nb, w.data_ptr(), eps
+        if rope is not None:
+            cos, sin, period = rope
+            _chk_bf16(cos, sin)
+            if period not in (Lq, B * Lq) or cos.stride(0) != sin.stride(0) or cos.stride(1) != 1:
+                raise ValueError("ltxmi.attention: rope tables must be [Lq or B*Lq, H*dh] with one row stride")
+            a.rope_cos, a.rope_sin = cos.data_ptr(), sin.data_ptr()
+            a.rope_stride_l = cos.stride(0)
+            a.rope_stride_b = 0 if period == Lq else Lq * cos.stride(0)
+    elif rope is not None:
+        raise ValueError("ltxmi.attention: rope needs q_norm")
     tok = _prof_begin(("attention", B, H, Lq, Lk, dh))
     check(lib.ltxmi_attention_fwd_bf16(ctypes.byref(a), _stream()), "ltxmi_attention_fwd_bf16")
     _prof_end(tok)

@@ -792,3 +792,56 @@ def test_attention_config_shapes_properties(B, H, N, dh):
     oc = ops.attention(q, kc, vc)
     rows = slice(1000, 1256)
     check(oc[:, rows], attn_truth(q[:, rows].cpu(), kc.cpu(), vc.cpu()), what=f"cross Lk 512 at N{N} dh{dh}")
+
+
+# ------------------------------------------------------------- fused K1: QKV projection -> q_norm + RoPE on load
+@pytest.mark.parametrize("M,N,K,cols", [(300, 384, 128, 128), (6144, 4096, 256, 2048), (14976, 6144, 256, 2048)])
+def test_gemm_row_sums_of_squares(M, N, K, cols):
+    """gemm(..., rowsumsq=): per-(row, 64-column block) sums of squares of the STORED bf16 outputs for the columns
+    < cols (tile kernels and the persistent kernel), the output itself unchanged."""
+    from ltxmi import ops
+    a, w, b = rnd(M, K, seed=160), rnd(N, K, seed=161, scale=K ** -0.5), rnd(N, seed=162)
+    ss = torch.full((M, cols // 64 + 1), -7.0, dtype=torch.float32, device=DEV)      # one guard column
+    out = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), rowsumsq=ss, rowsumsq_cols=cols)
+    plain = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV))
+    assert torch.equal(out, plain)
+    want = out[:, :cols].float().reshape(M, cols // 64, 64).pow(2).sum(-1)
+    torch.testing.assert_close(ss[:, : cols // 64], want, rtol=1e-5, atol=1e-6)
+    assert (ss[:, cols // 64] == -7.0).all()                                          # nothing written past the q columns
+
+
+@pytest.mark.parametrize("B,H,N,per_sample_tables", [(3, 32, 1400, False), (2, 32, 2100, True)])
+def test_attention_q_norm_and_rope_on_load(B, H, N, per_sample_tables):
+    """The attention kernel finishing q while it loads it (RMSNorm over all heads from the GEMM's partial sums, weight,
+    interleaved RoPE) against the two-pass form (rmsnorm_rope_ on q, then attention) and against the oracle."""
+    from ltxmi import ops
+    from oracle import dit
+    dh, D = 64, H * 64
+    assert ops.attention_fuses_qnorm(B, H, N, N, dh)
+    g = torch.Generator(device=DEV).manual_seed(170)
+    qkv = (torch.randn(B * N, 3 * D, generator=g, device=DEV) * 1.7).to(BF)
+    wq = (1.0 + 0.1 * torch.randn(D, generator=g, device=DEV)).to(BF)
+    wk = (1.0 + 0.1 * torch.randn(D, generator=g, device=DEV)).to(BF)
+    rows = B * N if per_sample_tables else N
+    ang = torch.rand(rows, D // 2, generator=g, device=DEV) * 6.28
+    cos = ang.cos().repeat_interleave(2, dim=-1).to(BF)
+    sin = ang.sin().repeat_interleave(2, dim=-1).to(BF)
+    ss = qkv[:, :D].float().reshape(B * N, D // 64, 64).pow(2).sum(-1).contiguous()
+    ref = qkv.clone()
+    ops.rmsnorm_rope_(ref[:, :D], wq, 1e-5, cos, sin, rows)
+    ops.rmsnorm_rope_(ref[:, D:2 * D], wk, 1e-5, cos, sin, rows)
+    v5 = ref.view(B, N, 3, H, dh)
+    two_pass = ops.attention(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2])
+    fused_in = qkv.clone()
+    fused_in[:, D:2 * D] = ref[:, D:2 * D]                            # k finished by its own pass, q left raw
+    f5 = fused_in.view(B, N, 3, H, dh)
+    fused = ops.attention(f5[:, :, 0], f5[:, :, 1], f5[:, :, 2], q_norm=(ss, wq, 1e-5), rope=(cos, sin, rows))
+    check(fused, two_pass.float(), rel_l2=2e-3, maxrel=1.6e-2, what="q finished on load vs two passes")
+    # a band of rows against the oracle (fp32 norm + RoPE + attention on the same bf16 inputs)
+    sel = slice(N - 200, N)
+    q32 = qkv[:, :D].float().cpu().view(B, N, D)
+    qn = q32 * torch.rsqrt(q32.pow(2).mean(-1, keepdim=True) + 1e-5) * wq.float().cpu()
+    tab = (cos.float().cpu().view(-1, N, D), sin.float().cpu().view(-1, N, D))
+    qr = dit.apply_rotary_emb(qn, tab)
+    truth = attn_truth(qr.view(B, N, H, dh)[:, sel], v5[:, :, 1].cpu(), v5[:, :, 2].cpu())
+    check(fused[:, sel], truth, what="q finished on load vs oracle")

@@ -346,21 +346,24 @@ def test_vae_tiled_decode_matches_oracle_tiling():
     v = build_vae(cfg, sd)
     # z-tiling (tile = 4+1 latent frames)
     z = torch.randn(1, 128, 7, 2, 2, generator=torch.Generator().manual_seed(10)).to(BF)
+    sdb = {k: (x.to(BF) if x.is_floating_point() and x.dim() > 0 else x) for k, x in sd.items()}
     truth = ov.decode(sd, cfg, z.float(), ts, use_z_tiling=True, z_sample_size=4).float()
+    eager = ov.decode(sdb, cfg, z, ts, use_z_tiling=True, z_sample_size=4).float()
     v.enable_z_tiling(4)
     out = v.decode(z.to(DEV), return_dict=False, target_shape=(1, 3, 49, 64, 64), timestep=ts.to(DEV))[0]
     v.disable_z_tiling()
     assert out.dtype == torch.float16 and out.shape == truth.shape
-    assert rel(out, truth) < 2e-2
+    assert_parity(out, truth, eager, "z-tiled decode")
     # hw-tiling with 64-px tiles
     z = torch.randn(1, 128, 2, 3, 4, generator=torch.Generator().manual_seed(11)).to(BF)
     truth = ov.decode(sd, cfg, z.float(), ts, use_hw_tiling=True, tile_sample_min_size=64)
+    eager = ov.decode(sdb, cfg, z, ts, use_hw_tiling=True, tile_sample_min_size=64)
     v.set_tiling_params(sample_size=64, overlap_factor=0.25)
     v.enable_hw_tiling()
     out = v.decode(z.to(DEV), return_dict=False, target_shape=(1, 3, 9, 96, 128), timestep=ts.to(DEV))[0]
     v.disable_hw_tiling()
     assert out.shape == truth.shape
-    assert rel(out, truth) < 2e-2
+    assert_parity(out, truth, eager, "hw-tiled decode")
 
 
 @pytest.mark.parametrize("style", ["a", "b"])
@@ -584,8 +587,9 @@ def test_pipeline_image_to_video_two_steps():
     import ltxmi
     from oracle import conditioning as oc, dit, sched, vae_encoder as oe
     heads, dh, layers, caption, T = 2, 64, 2, 128, 32
+    # causal_temporal_positioning = True as in the 0.9.5+ checkpoints' metadata (the t2v tests run the 2B default, False)
     cfg = dict(dit.default_2b_config(), num_attention_heads=heads, attention_head_dim=dh, num_layers=layers,
-               cross_attention_dim=heads * dh, caption_channels=caption)
+               cross_attention_dim=heads * dh, caption_channels=caption, causal_temporal_positioning=True)
     sd32 = {k: v.to(BF).float() for k, v in dit.init_state_dict(cfg, seed=7).items()}
     vcfg, vsd = vae_case("b", with_encoder=True)
     H, W, F_ = 64, 96, 17
@@ -600,30 +604,36 @@ def test_pipeline_image_to_video_two_steps():
     spec = [(img, 0, 1.0), (single, 8, 0.8)]
     gs, stg, rs, skip_blocks, steps, ns = 3.0, 1.0, 0.7, [1], 2, 0.15
 
-    # ---- oracle loop (fp32), noise drawn from a twin of the device generator in the product's order
-    twin = torch.Generator(device=DEV).manual_seed(41)
-    draw = lambda shape: torch.randn(tuple(shape), generator=twin, device=DEV, dtype=torch.float32).cpu()  # noqa: E731
-    tsch = sched.set_timesteps(steps, (1, 128, f, h, w))
-    lat, pc, mask, n_extra = oc.prepare_conditioning(
-        [oc.ConditioningItem(m.float(), fr, s) for m, fr, s in spec], sched.unpatchify(lat0, f, h, w).clone(),
-        F_, H, W, encode=lambda m: oe.vae_encode(vsd, vcfg, m), noise_fn=draw)
-    frac = pc.to(torch.float32)
-    frac[:, 0] = frac[:, 0] * (1.0 / 25.0)
-    fc = dit.precompute_freqs_cis(frac, cfg, torch.float32)
-    skip = dit.create_skip_layer_mask(layers, 1, 3, 2, skip_blocks, torch.float32)
-    emb = torch.cat([neg, pos, pos]).float()
-    msk = torch.cat([nmask, pmask, pmask])
-    init = lat.clone()
-    for t in tsch:
-        lat = oc.add_noise_to_image_conditioning_latents(t, init, lat, ns, mask, draw(lat.shape))
-        cur_t = oc.per_token_timestep(t, mask, 3)
-        npred = dit.transformer3d_forward(sd32, cfg, torch.cat([lat] * 3), fc, emb, cur_t,
-                                          encoder_attention_mask=msk, latent_shape=(f, h, w),
-                                          skip_layer_mask=skip, skip_layer_strategy=dit.ATTENTION_VALUES)
-        v = sched.guidance(npred, 3, gs, stg, rs, True, True, True)
-        lat = sched.denoising_step(tsch, lat, v, cur_t[:1], mask, t)
-    assert n_extra == h * w
-    truth = sched.unpatchify(lat[:, n_extra:], f, h, w)
+    # ---- oracle loop (fp32 = truth; DiT in bf16 = the reference's eager rendering), noise drawn from a twin of the
+    # device generator in the product's order
+    def oracle(dtype):
+        twin = torch.Generator(device=DEV).manual_seed(41)
+        draw = lambda shape: torch.randn(tuple(shape), generator=twin, device=DEV, dtype=torch.float32).cpu()  # noqa: E731
+        sd = {k: v.to(dtype) for k, v in sd32.items()}
+        tsch = sched.set_timesteps(steps, (1, 128, f, h, w))
+        lat, pc, mask, n_extra = oc.prepare_conditioning(
+            [oc.ConditioningItem(m.float(), fr, s) for m, fr, s in spec], sched.unpatchify(lat0, f, h, w).clone(),
+            F_, H, W, encode=lambda m: oe.vae_encode(vsd, vcfg, m), noise_fn=draw,
+            causal_fix=cfg["causal_temporal_positioning"])
+        frac = pc.to(torch.float32)
+        frac[:, 0] = frac[:, 0] * (1.0 / 25.0)
+        fc = dit.precompute_freqs_cis(frac, cfg, dtype)
+        skip = dit.create_skip_layer_mask(layers, 1, 3, 2, skip_blocks, dtype)
+        emb = torch.cat([neg, pos, pos]).to(dtype)
+        msk = torch.cat([nmask, pmask, pmask])
+        init = lat.clone()
+        for t in tsch:
+            lat = oc.add_noise_to_image_conditioning_latents(t, init, lat, ns, mask, draw(lat.shape))
+            cur_t = oc.per_token_timestep(t, mask, 3)
+            npred = dit.transformer3d_forward(sd, cfg, torch.cat([lat.to(dtype)] * 3), fc, emb, cur_t,
+                                              encoder_attention_mask=msk, latent_shape=(f, h, w),
+                                              skip_layer_mask=skip, skip_layer_strategy=dit.ATTENTION_VALUES)
+            v = sched.guidance(npred.float(), 3, gs, stg, rs, True, True, True)
+            lat = sched.denoising_step(tsch, lat, v, cur_t[:1], mask, t)
+        assert n_extra == h * w
+        return sched.unpatchify(lat[:, n_extra:], f, h, w), n_extra
+
+    (truth, n_extra), (eager, _) = oracle(torch.float32), oracle(BF)
 
     m = build_model(cfg, sd32)
     pipe = ltxmi.LTXVideoPipeline(m, ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1),
@@ -636,11 +646,14 @@ def test_pipeline_image_to_video_two_steps():
                image_cond_noise_scale=ns, sample_conditioning_posterior=False,
                generator=torch.Generator(device=DEV).manual_seed(41))
     assert out.shape == truth.shape == (1, 128, f, h, w)
-    e = rel(out, truth)
-    # the hard-conditioned first frame stays the (noised) encoder output
-    e0 = rel(out[:, :, 0], truth[:, :, 0])
-    print(f"i2v pipeline 2 steps: rel L2 {e:.3e} (first frame {e0:.3e})")
-    assert e < 2e-2 and e0 < 2e-2
+    # the conditioning latents come from the bf16 encoder kernels on our side and from the fp32 oracle encoder on both
+    # oracle sides (measured alone in test_vae_encode: ~8e-3 vs the eager encoder's ~1.1e-2); that part of our error is
+    # not in `eager`, hence the wider additive term here
+    e, e_ref = rel(out, truth), rel(eager, truth)
+    e0 = rel(out[:, :, 0], truth[:, :, 0])          # the hard-conditioned first frame stays the (noised) encoder output
+    print(f"i2v pipeline 2 steps: rel L2 ours {e:.3e} / eager DiT {e_ref:.3e} (first frame {e0:.3e})")
+    assert torch.isfinite(out.float()).all()
+    assert e <= e_ref + 5 * RTOL and e0 <= 1.4e-2 + RTOL
 
 
 def test_multiscale_pipeline_two_passes():
@@ -672,30 +685,39 @@ def test_multiscale_pipeline_two_passes():
     twin = torch.Generator(device=DEV).manual_seed(51)
     draw = lambda shape: torch.randn(tuple(shape), generator=twin, device=DEV, dtype=torch.float32).cpu()  # noqa: E731
 
-    def oracle_pass(lat, f, h, w, ts, kw):
+    def oracle_pass(lat, f, h, w, ts, kw, dtype):
         gs, stg, rs, skips, do_cfg, do_stg, do_rs = pc.guidance_tables(
             [float(x) for x in ts], kw["guidance_scale"], kw["stg_scale"], kw["rescaling_scale"],
             kw["skip_block_list"], kw["guidance_timesteps"])
         nc = 1 + int(do_cfg) + int(do_stg)
-        emb = torch.cat(([neg] if do_cfg else []) + [pos] + ([pos] if do_stg else [])).float()
+        sd = {k: v.to(dtype) for k, v in sd32.items()}
+        emb = torch.cat(([neg] if do_cfg else []) + [pos] + ([pos] if do_stg else [])).to(dtype)
         msk = torch.cat(([nmask] if do_cfg else []) + [pmask] + ([pmask] if do_stg else []))
-        fc = dit.precompute_freqs_cis(sched.fractional_coords(f, h, w, 1, 25.0), cfg, torch.float32)
+        pix = sched.latent_to_pixel_coords(sched.get_latent_coords(f, h, w, 1),
+                                           causal_fix=cfg.get("causal_temporal_positioning", False)).to(torch.float32)
+        pix[:, 0] = pix[:, 0] * (1.0 / 25.0)
+        fc = dit.precompute_freqs_cis(pix, cfg, dtype)
         for i, t in enumerate(ts):
-            skip = dit.create_skip_layer_mask(layers, 1, nc, nc - 1, skips[i], torch.float32) if (do_stg and skips) else None
-            npred = dit.transformer3d_forward(sd32, cfg, torch.cat([lat] * nc), fc, emb, t.expand(nc).unsqueeze(-1),
+            skip = dit.create_skip_layer_mask(layers, 1, nc, nc - 1, skips[i], dtype) if (do_stg and skips) else None
+            npred = dit.transformer3d_forward(sd, cfg, torch.cat([lat.to(dtype)] * nc), fc, emb, t.expand(nc).unsqueeze(-1),
                                               encoder_attention_mask=msk, latent_shape=(f, h, w),
                                               skip_layer_mask=skip, skip_layer_strategy=dit.ATTENTION_VALUES)
-            v = sched.guidance(npred, nc, gs[i], stg[i], rs[i], do_cfg, do_stg, do_rs)
+            v = sched.guidance(npred.float(), nc, gs[i], stg[i], rs[i], do_cfg, do_stg, do_rs)
             lat = sched.denoising_step(ts, lat, v, t.expand(1).unsqueeze(-1), None, t)
         return sched.unpatchify(lat, f, h, w)
 
-    ts1 = pc.retrieve_timesteps(3, (1, 128, f, h, w))
-    lat1 = oracle_pass(draw((1, f * h * w, 128)), f, h, w, ts1, first)
-    up = ou.adain_filter_latent(ou.upsample_latents(usd, ucfg, lat1, stats), lat1)
     shape2 = (1, 128, f, 2 * h, 2 * w)
+    ts1 = pc.retrieve_timesteps(3, (1, 128, f, h, w))
     ts2 = pc.retrieve_timesteps(4, shape2, skip_initial_inference_steps=2)
-    start = pc.prepare_latents(up, float(ts2[0]), draw((1, f * 4 * h * w, 128)), shape2)
-    truth = oracle_pass(sched.patchify(start)[0], f, 2 * h, 2 * w, ts2, second)
+    n1, n2 = draw((1, f * h * w, 128)), draw((1, f * 4 * h * w, 128))
+
+    def oracle_two_passes(dtype):                       # the upsampler bridge stays fp32 on both oracle sides
+        lat1 = oracle_pass(n1, f, h, w, ts1, first, dtype)
+        up = ou.adain_filter_latent(ou.upsample_latents(usd, ucfg, lat1, stats), lat1)
+        start = pc.prepare_latents(up, float(ts2[0]), n2, shape2)
+        return oracle_pass(sched.patchify(start)[0], f, 2 * h, 2 * w, ts2, second, dtype)
+
+    truth, eager = oracle_two_passes(torch.float32), oracle_two_passes(BF)
 
     m = build_model(cfg, sd32)
     ups = ltxmi.LatentUpsampler.from_config(ucfg)
@@ -711,9 +733,11 @@ def test_multiscale_pipeline_two_passes():
              generator=torch.Generator(device=DEV).manual_seed(51))
     assert out.shape == truth.shape == shape2
     torch.testing.assert_close(torch.tensor(vp.scheduler.host_timesteps), ts2, rtol=1e-6, atol=1e-7)
-    e = rel(out, truth)
-    print(f"multi-scale 2 passes: rel L2 {e:.3e}")
-    assert e < 2e-2
+    # our bf16 LatentUpsampler kernels sit between the passes (alone: 7.7e-3 vs the eager upsampler's 1.03e-2,
+    # test_latent_upsampler_and_bridge); both oracle sides run that bridge in fp32, hence the wider additive term
+    e, e_ref = rel(out, truth), rel(eager, truth)
+    print(f"multi-scale 2 passes: rel L2 ours {e:.3e} / eager DiT {e_ref:.3e}")
+    assert torch.isfinite(out.float()).all() and e <= e_ref + 5 * RTOL
     # the exact eliminations (rows whose guidance scale is zero at a step; the STG row before its first
     # skipped block) do not change a single bit
     plain = ms(0.5, first, second, height=128, width=192, num_frames=9, prompt_embeds=pos.to(DEV),
