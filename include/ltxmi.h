@@ -82,6 +82,10 @@ typedef struct ltxmi_gemm_args {
      * RMSNorm (over ALL heads, attention.py:478-479,1040-1041) + RoPE (:960-975,1053-1055) while it loads Q,
      * so q needs no pass of its own between the projection and attention.  NULL = off. */
     float*      rowsumsq; int32_t rowsumsq_cols; int64_t rowsumsq_ld;
+    /* Optional: A's K axis cut into blocks of a_kblock elements that lie a_kblock_stride elements apart (element k of
+     * row m at A[(k / a_kblock) * a_kblock_stride + m * lda + k % a_kblock]).  The receive buffer of the Ulysses return
+     * all-to-all, [P source ranks][rows][D / P], is the A operand of to_out in place.  0 = plain row-major A. */
+    int32_t     a_kblock; int64_t a_kblock_stride;
 } ltxmi_gemm_args;
 
 int ltxmi_gemm_bf16(const ltxmi_gemm_args* args, void* stream);
@@ -143,12 +147,25 @@ typedef struct ltxmi_attn_args {
     const float* q_rowsumsq; int64_t q_rowsumsq_stride_b, q_rowsumsq_stride_l; int32_t q_rowsumsq_blocks;
     const void*  q_norm_weight; float q_norm_eps;
     const void*  rope_cos; const void* rope_sin; int64_t rope_stride_b, rope_stride_l;
+    /* Optional: the output's token axis in segments of o_segment_len tokens lying o_stride_segment elements apart
+     * (token l of batch b at o[(l / o_segment_len) * o_stride_segment + b * o_stride_b + (l % o_segment_len) * o_stride_l]):
+     * the send buffer of the Ulysses return all-to-all, [P destination ranks][B][N / P][H dh], written in place.  0 = off. */
+    int32_t o_segment_len; int64_t o_stride_segment;
 } ltxmi_attn_args;
 
 int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* args, void* stream);
 /* 1 if ltxmi_attention_fwd_bf16 can normalise + rotate q on load for this shape (large head_dim-64 self-attention
  * without a key bias), else 0: the caller then runs ltxmi_rmsnorm_rope_bf16 on q as a pass of its own. */
 int ltxmi_attention_fuses_qnorm(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias);
+
+/* Ulysses send buffer in one pass (sequence-parallel self-attention, xdit_context_parallel.py:149-184 of the reference
+ * for Wan; here for the LTX DiT): q/k RMSNorm(weight) + interleaved RoPE exactly as ltxmi_rmsnorm_rope_bf16 and v,
+ * read from the packed projection qkv [B*Nl, 3 D] (row stride ld, row = b * Nl + n) and written destination-major:
+ *   out[P][Nl][B][3][D / P]  (destination rank = head group of the channel).
+ * After all_to_all_single, rank r holds [P*Nl][B][3][D/P]: its heads over all tokens, uniform strides. */
+int ltxmi_qkv_norm_rope_pack_bf16(const void* qkv, int64_t ld, int32_t B, int32_t Nl, int32_t D, int32_t P,
+                                  const void* q_weight, const void* k_weight, float eps, const void* cos_tab,
+                                  const void* sin_tab, int64_t ld_tab, int32_t rope_period, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Small elementwise helpers on the DiT path.

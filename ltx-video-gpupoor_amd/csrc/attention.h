@@ -18,6 +18,15 @@ struct AttnParams {
     const float* q_ss; int64_t q_ss_sb, q_ss_sl; int q_ss_n;
     const uint16_t* q_w; float q_eps;
     const uint16_t* rope_cos; const uint16_t* rope_sin; int64_t rope_sb, rope_sl;
+    // optional: the output's token axis is cut into segments of o_seg tokens, o_sseg elements apart (Ulysses: the
+    // return all-to-all's send buffer [P dst][B][N / P][H dh]); 0 = one segment
+    int o_seg; int64_t o_sseg;
+
+    __device__ __forceinline__ int64_t o_row(int row) const {
+        if (o_seg <= 0) return (int64_t)row * o_sl;
+        const int sg = row / o_seg;
+        return (int64_t)sg * o_sseg + (int64_t)(row - sg * o_seg) * o_sl;
+    }
 };
 
 // attention_pipe.hip: software-pipelined self-attention (head_dim 64, no key bias).

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
         for (int t = 0; t < 32 / RPI; ++t) {
             const int row = t * RPI + lane / LPR, chunk = lane % LPR;
             const u32x4 w = *(const u32x4*)(scr + row * C::ROW_BYTES + ((chunk ^ (row & 7)) << 4));
-            if (q0 + row < p.Lq) *(u32x4*)(ob + (int64_t)(q0 + row) * p.o_sl + chunk * 8) = w;
+            if (q0 + row < p.Lq) *(u32x4*)(ob + p.o_row(q0 + row) + chunk * 8) = w;
         }
     }
 }
@@ -509,6 +509,9 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     p.q_w = (const uint16_t*)a->q_norm_weight; p.q_eps = a->q_norm_eps;
     p.rope_cos = (const uint16_t*)a->rope_cos; p.rope_sin = (const uint16_t*)a->rope_sin;
     p.rope_sb = a->rope_stride_b; p.rope_sl = a->rope_stride_l;
+    p.o_seg = a->o_segment_len; p.o_sseg = a->o_stride_segment;
+    LTXMI_REQUIRE(a->o_segment_len >= 0 && a->o_stride_segment % 8 == 0, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_attention_fwd_bf16: bad output segment geometry");
     const bool pipe_ok = LTXMI_ATTN_PIPE && attn_pipe_takes(a->B, a->H, a->Lq, a->Lk, a->head_dim, a->key_bias != nullptr);
     if (a->q_rowsumsq) {
         LTXMI_REQUIRE(pipe_ok, LTXMI_ERR_UNSUPPORTED,

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
         for (int t = 0; t < 4; ++t) {
             const int row = t * 8 + (L.lane >> 3), chunk = L.lane & 7;
             const u32x4 w = *(const u32x4*)(scr + row * ROW_BYTES + ((chunk ^ (row & 7)) << 4));
-            if (q0 + row < p.Lq) *(u32x4*)(ob + (int64_t)(q0 + row) * p.o_sl + chunk * 8) = w;
+            if (q0 + row < p.Lq) *(u32x4*)(ob + p.o_row(q0 + row) + chunk * 8) = w;
         }
     };
     store(A, 0);

@@ -54,6 +54,16 @@ struct GemmParams {
     const uint16_t* res; int res_ch;
     // EPI_SUMSQ: fp32 [M, sumsq_ld] partial row sums of squares of the bf16 outputs, one per 64-column block
     float* sumsq; int sumsq_cols; int64_t sumsq_ld;
+    // A whose K axis is cut into blocks of a_kblk elements lying a_kblk_stride elements apart (0 = plain): the receive
+    // buffer of the Ulysses return all-to-all, [P source ranks][rows][D / P], is consumed in place by to_out
+    int a_kblk; int64_t a_kblk_stride;
+
+    __device__ __forceinline__ int64_t a_koff(int kt) const {       // element offset of k-tile kt inside a row of A
+        const int kk = kt * 64;
+        if (a_kblk <= 0) return kk;
+        const int blk = kk / a_kblk;
+        return (int64_t)blk * a_kblk_stride + (kk - blk * a_kblk);
+    }
 };
 
 constexpr int EPI_D2S = 4;   // internal: conv + pixel-shuffle(2,2,2) scatter (+ residual)
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
             const int j = g - A_INSTR;
             glds16(b_src[j] + kt * BK, sb + (wave * B_INSTR + j) * 1024);
         } else if (MODE == 0) {
-            glds16(a_src[g] + kt * BK, sa + (wave * A_INSTR + g) * 1024);
+            glds16(a_src[g] + p.a_koff(kt), sa + (wave * A_INSTR + g) * 1024);
         } else {
             // K index = tap * Cin + cin; a 64-wide K-tile never straddles taps (Cin % 64 == 0)
             const int kk = kt * BK;
@@ -435,8 +445,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     // (the resource type can be neither a struct member, nor bound to a reference, nor captured by a
     // lambda in the host pass: descriptors are plain locals passed BY VALUE)
     auto rsrc_a = [&](int m0) {
+        // (K-blocked A: the descriptor spans all blocks; rows past M then read other rows' data instead of zeros --
+        // their results are never stored)
+        const int64_t span = p.a_kblk > 0 ? (int64_t)(p.K / p.a_kblk - 1) * p.a_kblk_stride + p.a_kblk : p.K;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0,
-                                                 (int)(((int64_t)(min(BM, p.M - m0) - 1) * p.lda + p.K) * 2), 0x00020000);
+                                                 (int)(((int64_t)(min(BM, p.M - m0) - 1) * p.lda + span) * 2), 0x00020000);
     };
     auto rsrc_w = [&](int n0) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw), 0,
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
         char* sa = smem + buf * STAGE_BYTES;
         if (g < PPW_A) {
             const int q = wave * PPW_A + g;
-            blds16(ta, sa + q * 1024, aoff0 + (uint32_t)(q * a_step), kt * (BK * 2));
+            blds16(ta, sa + q * 1024, aoff0 + (uint32_t)(q * a_step), (int)(p.a_koff(kt) * 2));
         } else {
             const int q = wave * PPW_B + (g - PPW_A);
             blds16(tw, sa + A_BYTES + q * 1024, boff0 + (uint32_t)(q * b_step), kt * (BK * 2));
@@ -809,7 +822,7 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
                   "ltxmi_gemm_bf16: non-positive shape M=%d N=%d K=%d", a->M, a->N, a->K);
     LTXMI_REQUIRE(a->K % 64 == 0, LTXMI_ERR_UNSUPPORTED, "ltxmi_gemm_bf16: K=%d must be a multiple of 64", a->K);
     LTXMI_REQUIRE(a->N % 8 == 0, LTXMI_ERR_UNSUPPORTED, "ltxmi_gemm_bf16: N=%d must be a multiple of 8", a->N);
-    LTXMI_REQUIRE(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldc % 4 == 0 && a->lda >= a->K && a->ldw >= a->K &&
+    LTXMI_REQUIRE(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldc % 4 == 0 && (a->lda >= a->K || a->a_kblock > 0) && a->ldw >= a->K &&
                       a->ldc >= a->N,
                   LTXMI_ERR_UNSUPPORTED, "ltxmi_gemm_bf16: bad leading dimensions lda=%lld ldw=%lld ldc=%lld",
                   (long long)a->lda, (long long)a->ldw, (long long)a->ldc);
@@ -839,6 +852,15 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     p.tiles_m = p.tiles_n = 0;
     p.cB = p.cT = p.cH = p.cW = p.cCin = 1; p.oT = p.oH = p.oW = 1; p.sT = p.sHW = 1; p.tpad = 0; p.tzero = 0; p.pad_replicate = 0; p.res = nullptr; p.res_ch = 0;
     p.sumsq = a->rowsumsq; p.sumsq_cols = a->rowsumsq_cols; p.sumsq_ld = a->rowsumsq_ld;
+    p.a_kblk = a->a_kblock; p.a_kblk_stride = a->a_kblock_stride;
+    if (a->a_kblock) {
+        LTXMI_REQUIRE(a->a_kblock > 0 && a->a_kblock % 64 == 0 && a->K % a->a_kblock == 0 && a->a_kblock_stride % 8 == 0 &&
+                          a->lda >= a->a_kblock,
+                      LTXMI_ERR_INVALID_ARG, "ltxmi_gemm_bf16: a_kblock=%d must be a multiple of 64 that divides K, lda >= a_kblock",
+                      a->a_kblock);
+        LTXMI_REQUIRE(((int64_t)(a->K / a->a_kblock - 1) * a->a_kblock_stride + (int64_t)256 * a->lda) * 2 < (1ll << 31),
+                      LTXMI_ERR_UNSUPPORTED, "ltxmi_gemm_bf16: K-blocked A spans more than 2 GiB per tile");
+    }
     if (a->rowsumsq) {
         LTXMI_REQUIRE(a->epilogue == LTXMI_EPI_NONE, LTXMI_ERR_UNSUPPORTED, "ltxmi_gemm_bf16: rowsumsq needs the plain epilogue");
         LTXMI_REQUIRE(a->rowsumsq_cols > 0 && a->rowsumsq_cols % 64 == 0 && a->rowsumsq_cols <= a->N &&
@@ -917,7 +939,7 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
     p.C = (uint16_t*)a->y; p.ldc = a->Cout;
     p.M = (int)M; p.N = a->Cout; p.K = 9 * kt * a->Cin;
     p.R = nullptr; p.ldr = 0; p.gate_table = nullptr; p.gate_temb = nullptr; p.gate_ld = 0; p.rows_per_group = 1;
-    p.sumsq = nullptr; p.sumsq_cols = 0; p.sumsq_ld = 0;
+    p.sumsq = nullptr; p.sumsq_cols = 0; p.sumsq_ld = 0; p.a_kblk = 0; p.a_kblk_stride = 0;
     p.tiles_m = p.tiles_n = 0;
     p.cB = a->B; p.cT = a->T; p.cH = a->H; p.cW = a->W; p.cCin = a->Cin;
     p.oT = oT; p.oH = oH; p.oW = oW; p.sT = sT; p.sHW = sHW;

@@ -259,6 +259,78 @@ __global__ __launch_bounds__(256) void layernorm_affine_kernel(const uint16_t* _
     }
 }
 
+// ---------------- Ulysses send buffer: q/k RMSNorm(weight) + RoPE and v, written destination-major
+// One pass over a row of the packed projection [q | k | v] (3 D channels): q and k are normalised + rotated exactly as
+// rmsnorm_rope_kernel does, v is copied, and every 16-byte chunk goes straight to its place in the all-to-all send
+// buffer  [P dst][Nl tokens][B][3][D / P]  (destination rank = head group of the channel).  Token-major inside a
+// destination's chunk: after the exchange rank r holds [N = P Nl][B][3][D / P], i.e. q, k, v of ITS heads over ALL
+// tokens with uniform batch / token strides -- the attention kernel reads that in place, no unpack copy.
+template <int NCH>
+__global__ __launch_bounds__(256) void qkv_norm_rope_pack_kernel(const uint16_t* __restrict__ x, int64_t ldx, int B, int Nl,
+                                                                 int D, int P, const uint16_t* __restrict__ wq,
+                                                                 const uint16_t* __restrict__ wk, float eps,
+                                                                 const uint16_t* __restrict__ cs,
+                                                                 const uint16_t* __restrict__ sn, int64_t ld_tab,
+                                                                 int rope_period, uint16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);          // = b * Nl + n
+    if (row >= B * Nl) return;
+    const int b = row / Nl, n = row - b * Nl;
+    const int nchunk = D >> 3, Dp = D / P;
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    Chunk cq[NCH], ck[NCH];
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            cq[j] = load_chunk(xr + ch * 8);
+            ck[j] = load_chunk(xr + D + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sq += cq[j].v[e] * cq[j].v[e];
+                sk += ck[j].v[e] * ck[j].v[e];
+            }
+        }
+    }
+    sq = wave_sum(sq);
+    sk = wave_sum(sk);
+    const float rq = rsqrtf(sq / D + eps), rk = rsqrtf(sk / D + eps);
+    const int64_t trow = cs ? (int64_t)(row % rope_period) * ld_tab : 0;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            const int c0 = ch * 8;
+            const int p = c0 / Dp, cl = c0 - p * Dp;                        // destination rank, channel within its D / P
+            uint16_t* dst = out + ((((int64_t)p * Nl + n) * B + b) * 3) * Dp + cl;
+            const Chunk wqv = load_chunk(wq + c0), wkv = load_chunk(wk + c0);
+            Chunk oq, ok;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                oq.v[e] = cq[j].v[e] * rq * wqv.v[e];
+                ok.v[e] = ck[j].v[e] * rk * wkv.v[e];
+            }
+            if (cs) {
+                const Chunk co = load_chunk(cs + trow + c0), si = load_chunk(sn + trow + c0);
+                Chunk r2, r3;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    r2.v[e] = oq.v[e] * co.v[e] - oq.v[e + 1] * si.v[e];
+                    r2.v[e + 1] = oq.v[e + 1] * co.v[e + 1] + oq.v[e] * si.v[e + 1];
+                    r3.v[e] = ok.v[e] * co.v[e] - ok.v[e + 1] * si.v[e];
+                    r3.v[e + 1] = ok.v[e + 1] * co.v[e + 1] + ok.v[e] * si.v[e + 1];
+                }
+                oq = r2;
+                ok = r3;
+            }
+            store_chunk(dst, oq);
+            store_chunk(dst + Dp, ok);
+            *(u32x4*)(dst + 2 * Dp) = *(const u32x4*)(xr + 2 * D + c0);     // v: plain copy
+        }
+    }
+}
+
 static inline int nch_for(int D) { return D <= 512 ? 1 : (D <= 2048 ? 4 : 16); }
 
 }  // namespace ltxmi
@@ -317,6 +389,28 @@ extern "C" int ltxmi_rmsnorm_rope_bf16(void* x, int64_t ldx, int32_t rows, int32
                                        rows, D, (const uint16_t*)weight, eps, (const uint16_t*)cos_tab,
                                        (const uint16_t*)sin_tab, ld_tab, rope_period > 0 ? rope_period : 1))
     return check_launch("ltxmi_rmsnorm_rope_bf16");
+}
+
+extern "C" int ltxmi_qkv_norm_rope_pack_bf16(const void* qkv, int64_t ld, int32_t B, int32_t Nl, int32_t D, int32_t P,
+                                             const void* q_weight, const void* k_weight, float eps, const void* cos_tab,
+                                             const void* sin_tab, int64_t ld_tab, int32_t rope_period, void* out,
+                                             void* stream) {
+    LTXMI_REQUIRE(qkv && q_weight && k_weight && out, LTXMI_ERR_INVALID_ARG, "ltxmi_qkv_norm_rope_pack_bf16: NULL argument");
+    LTXMI_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr), LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_qkv_norm_rope_pack_bf16: cos and sin must both be given or both be NULL");
+    LTXMI_REQUIRE(B > 0 && Nl > 0 && D > 0 && P > 0, LTXMI_ERR_INVALID_ARG, "ltxmi_qkv_norm_rope_pack_bf16: non-positive size");
+    LTXMI_REQUIRE(D % (8 * P) == 0 && D <= 8192 && ld % 8 == 0 && ld >= 3 * D, LTXMI_ERR_UNSUPPORTED,
+                  "ltxmi_qkv_norm_rope_pack_bf16: D=%d must be a multiple of 8 * P (P=%d) and <= 8192, ld >= 3 D", D, P);
+    LTXMI_REQUIRE((int64_t)B * Nl < (1ll << 31) - 4, LTXMI_ERR_UNSUPPORTED, "ltxmi_qkv_norm_rope_pack_bf16: too many rows");
+    if (cos_tab) LTXMI_REQUIRE(rope_period > 0 && ld_tab % 8 == 0 && ld_tab >= D, LTXMI_ERR_INVALID_ARG,
+                               "ltxmi_qkv_norm_rope_pack_bf16: bad rope table geometry");
+    const int rows = B * Nl, grid = (rows + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_NCH(D, hipLaunchKernelGGL((qkv_norm_rope_pack_kernel<NCH>), dim3(grid), dim3(256), 0, s, (const uint16_t*)qkv,
+                                       ld, B, Nl, D, P, (const uint16_t*)q_weight, (const uint16_t*)k_weight, eps,
+                                       (const uint16_t*)cos_tab, (const uint16_t*)sin_tab, ld_tab,
+                                       rope_period > 0 ? rope_period : 1, (uint16_t*)out))
+    return check_launch("ltxmi_qkv_norm_rope_pack_bf16");
 }
 
 extern "C" int ltxmi_pixelnorm_ada_silu_bf16(const void* x, void* y, int64_t rows, int32_t C,

@@ -18,7 +18,8 @@ class GemmArgs(ctypes.Structure):
                 ("C", c_void_p), ("ldc", c_int64), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("epilogue", c_int), ("residual", c_void_p), ("ldr", c_int64), ("gate_table", c_void_p),
                 ("gate_temb", c_void_p), ("gate_ld", c_int64), ("rows_per_group", c_int), ("algo", c_int),
-                ("rowsumsq", c_void_p), ("rowsumsq_cols", c_int), ("rowsumsq_ld", c_int64)]
+                ("rowsumsq", c_void_p), ("rowsumsq_cols", c_int), ("rowsumsq_ld", c_int64),
+                ("a_kblock", c_int), ("a_kblock_stride", c_int64)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -31,7 +32,8 @@ class AttnArgs(ctypes.Structure):
                 ("softmax_scale", c_float),
                 ("q_rowsumsq", c_void_p), ("q_rowsumsq_stride_b", c_int64), ("q_rowsumsq_stride_l", c_int64),
                 ("q_rowsumsq_blocks", c_int), ("q_norm_weight", c_void_p), ("q_norm_eps", c_float),
-                ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("rope_stride_b", c_int64), ("rope_stride_l", c_int64)]
+                ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("rope_stride_b", c_int64), ("rope_stride_l", c_int64),
+                ("o_segment_len", c_int), ("o_stride_segment", c_int64)]
 
 
 class Conv3dArgs(ctypes.Structure):
@@ -53,6 +55,8 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ltxmi_rmsnorm_rope_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p,
                                         c_int64, c_int, c_void_p]),
+    "ltxmi_qkv_norm_rope_pack_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                              c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "ltxmi_attention_fwd_bf16": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "ltxmi_attention_fuses_qnorm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "ltxmi_silu_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -11,8 +11,8 @@ provides the same two entry points for the LTX DiT, written directly on ``torch.
     across heads, RoPE with sliced tables, cross-attention against the replicated 256 text tokens,
     FF), so rank r simply owns N/P contiguous tokens;
   * inside self-attention each rank owns H/P heads over ALL tokens: ONE packed all-to-all carries
-    q,k,v ([B, N/P, 3, H, dh] -> [B, N, 3, H/P, dh]) and one carries o back -- 2 collectives per
-    layer instead of xfuser's 4.  xGMI is point-to-point, so an all-to-all uses all 7 links of a GPU
+    q,k,v and one carries o back -- 2 collectives per layer instead of xfuser's 4 -- and both run on
+    the buffers the kernels write / read (no pack or unpack copies, see UlyssesAttnProcessor).  xGMI is point-to-point, so an all-to-all uses all 7 links of a GPU
     at once (each peer pair its own link) and is not ring/per-link bound;
   * the model output [B, N/P, C] is all-gathered once per forward.
 
@@ -69,15 +69,13 @@ def head_to_seq_shard(o, group=None):
     return recv.permute(1, 2, 0, 3, 4).reshape(B, Nl, world * Hl, dh)            # chunk i = heads of rank i
 
 
-def _default_attention(q, k, v, softmax_scale):
-    from . import ops
-    return ops.attention(q, k, v, softmax_scale=softmax_scale)
-
-
 def usp_attn_forward(qkv, softmax_scale, group=None, attn_fn: Optional[Callable] = None):
-    """Ulysses self-attention on a packed, already normed/roped projection buffer.
+    """Ulysses self-attention on a packed, already normed/roped projection buffer (generic form, any attention
+    function; the product path below is the zero-copy form of the same exchange).
     qkv: [B, N/P, 3, H, dh] -> returns [B, N/P, H, dh]."""
-    attn_fn = attn_fn or _default_attention
+    if attn_fn is None:
+        from . import ops
+        attn_fn = lambda q, k, v, scale: ops.attention(q, k, v, softmax_scale=scale)   # noqa: E731
     full = seq_to_head_shard(qkv, group)
     o = attn_fn(full[:, :, 0], full[:, :, 1], full[:, :, 2], softmax_scale)
     return head_to_seq_shard(o.contiguous(), group)
@@ -85,8 +83,19 @@ def usp_attn_forward(qkv, softmax_scale, group=None, attn_fn: Optional[Callable]
 
 # ------------------------------------------------------------------ processor + model forward
 class UlyssesAttnProcessor:
-    """Replaces AttnProcessor2_0 on ``attn1`` of every block (installed with
-    ``Attention.set_processor``): identical math, plus the two all-to-alls."""
+    """Replaces AttnProcessor2_0 on ``attn1`` of every block (installed with ``Attention.set_processor``): identical
+    math, plus the two all-to-alls -- which run directly on the buffers the kernels write and read:
+
+        QKV GEMM            [B*Nl, 3D]
+        qkv_norm_rope_pack  q/k RMSNorm + RoPE, v; every channel written to its destination rank's chunk
+                            send  [P dst][Nl][B][3][D/P]
+        all_to_all_single   recv  [P src][Nl][B][3][D/P] = [N][B][3][H/P][dh]: q, k, v of the local heads over ALL
+                            tokens with uniform strides -- the attention kernel reads them in place
+        attention           writes o into the return exchange's send buffer  [P dst][B][Nl][D/P]  (segmented token axis)
+        all_to_all_single   recv  [P src][B*Nl][D/P]: the K-blocked A operand of to_out, consumed in place
+        to_out GEMM (+ gate + residual epilogue)
+
+    No pack / unpack copy exists anywhere (the first version of this path spent 10 % of a step in them)."""
 
     def __init__(self, group=None):
         self.group = group
@@ -99,32 +108,47 @@ class UlyssesAttnProcessor:
         hidden_states = hidden_states_wrapper[0]
         hidden_states_wrapper.clear()
         assert encoder_hidden_states is None, "UlyssesAttnProcessor is for self-attention"
+        P = dist.get_world_size(self.group)
         B, Nl, _ = hidden_states.shape
         D, H = attn.inner_dim, attn.heads
         dh = D // H
+        if H % P != 0:
+            raise ValueError(f"heads {H} not divisible by the sequence-parallel degree {P}")
+        Hl, Dp = H // P, D // P
         wqkv, bqkv, _, _ = attn.packed()
-        qkv = ops.gemm(hidden_states.reshape(B * Nl, -1), wqkv, bqkv)
+        qkv = ops.gemm(hidden_states.reshape(B * Nl, -1), wqkv, bqkv)                       # [B*Nl, 3D]
         cos, sin = freqs_cis                                   # already sliced to the local tokens
         cos2, sin2 = cos.reshape(-1, D), sin.reshape(-1, D)
-        ops.rmsnorm_rope_(qkv[:, :D], attn.q_norm.weight, attn.q_norm.eps, cos2, sin2, cos2.shape[0])
-        ops.rmsnorm_rope_(qkv[:, D:2 * D], attn.k_norm.weight, attn.k_norm.eps, cos2, sin2, cos2.shape[0])
-        a4 = usp_attn_forward(qkv.view(B, Nl, 3, H, dh), attn.scale, self.group)
-        a3 = a4.reshape(B, Nl, D)
+        send = ops.qkv_norm_rope_pack(qkv, B, Nl, D, P, attn.q_norm.weight, attn.k_norm.weight, attn.q_norm.eps,
+                                      cos2, sin2, cos2.shape[0])                            # [P, Nl, B, 3, Dp]
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        full = recv.view(P * Nl, B, 3, Hl, dh)                                              # [N, B, 3, Hl, dh]
+        q, k, v = (full[:, :, i].permute(1, 0, 2, 3) for i in range(3))                     # [B, N, Hl, dh] views
+        osend = torch.empty((P, B, Nl, Hl, dh), dtype=qkv.dtype, device=qkv.device)
+        ops.attention(q, k, v, out=osend[0], softmax_scale=attn.scale, out_segments=(Nl, B * Nl * Dp))
+        orecv = torch.empty_like(osend)
+        dist.all_to_all_single(orecv, osend, group=self.group)                              # [P src][B*Nl][Dp]
         host_mask = _host_mask(skip_layer_mask) if skip_layer_mask is not None else None
         if host_mask is not None and any(m != 1.0 for m in host_mask):
+            # STG blends (attention.py:1127-1141) on the K-blocked layout, one head group at a time
             m_dev = skip_layer_mask.reshape(B).to(torch.float32)
-            if skip_layer_strategy == SkipLayerStrategy.AttentionValues:
-                ops.stg_blend_(a3, qkv.view(B, Nl, 3 * D)[:, :, 2 * D:], m_dev)
-            elif skip_layer_strategy == SkipLayerStrategy.AttentionSkip:
-                ops.stg_blend_(a3, hidden_states, m_dev)
+            for p in range(P):
+                a3 = orecv[p].view(B, Nl, Dp)
+                if skip_layer_strategy == SkipLayerStrategy.AttentionValues:
+                    ops.stg_blend_(a3, qkv.view(B, Nl, 3 * D)[:, :, 2 * D + p * Dp: 2 * D + (p + 1) * Dp], m_dev)
+                elif skip_layer_strategy == SkipLayerStrategy.AttentionSkip:
+                    ops.stg_blend_(a3, hidden_states[:, :, p * Dp:(p + 1) * Dp], m_dev)
         w_o, b_o = attn.to_out[0].weight, attn.to_out[0].bias
+        a_blk0 = orecv[0].view(B * Nl, Dp)
+        kb = dict(a_kblock=Dp, a_kblock_stride=B * Nl * Dp) if P > 1 else {}
         if fused_residual is not None:
             residual, gate_table, gate_temb, rpg = fused_residual
-            ops.gemm(a3.reshape(B * Nl, D), w_o, b_o, out=residual.reshape(B * Nl, -1),
+            ops.gemm(a_blk0, w_o, b_o, out=residual.reshape(B * Nl, -1),
                      epilogue=ops.EPI_GATE_RESIDUAL, residual=residual.reshape(B * Nl, -1),
-                     gate_table=gate_table, gate_temb=gate_temb, rows_per_group=rpg)
+                     gate_table=gate_table, gate_temb=gate_temb, rows_per_group=rpg, **kb)
             return residual
-        return ops.gemm(a3.reshape(B * Nl, D), w_o, b_o).view(B, Nl, -1)
+        return ops.gemm(a_blk0, w_o, b_o, **kb).view(B, Nl, -1)
 
 
 def enable_sequence_parallel(model, group=None):
@@ -152,9 +176,23 @@ def usp_dit_forward(model, hidden_states, freqs_cis, encoder_hidden_states=None,
             raise ValueError("per-token timesteps need whole latent frames per rank")
         timestep = shard_tokens(timestep, rank, world)
         latent_shape = (latent_shape[0] // world,) + tuple(latent_shape[1:])
+    # The reference's cooperative cancel (``ltxv_model._interrupt`` polled before every block, transformer3d.py:468-469)
+    # is a per-process flag: under sequence parallelism one rank leaving the block loop while the others wait in an
+    # all-to-all would hang the group.  The flag is therefore agreed on ONCE per forward, here (MAX all-reduce), and the
+    # blocks run with a frozen copy of the agreed value.
+    holder = kw.pop("ltxv_model", None)
+    if holder is not None:
+        flag = torch.tensor([1 if getattr(holder, "_interrupt", False) else 0], dtype=torch.int32, device=hidden_states.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()):
+            return [None]
+        kw["ltxv_model"] = _Frozen()
     out = model(hs, freqs_cis=fc, encoder_hidden_states=encoder_hidden_states, timestep=timestep,
                 encoder_attention_mask=encoder_attention_mask, skip_layer_mask=skip_layer_mask,
                 skip_layer_strategy=skip_layer_strategy, latent_shape=latent_shape, return_dict=False, **kw)
-    if out[0] is None:
-        return [None]
     return (gather_tokens(out[0], group),)
+
+
+class _Frozen:
+    """Stand-in ``ltxv_model`` for the block loop under sequence parallelism: never interrupts mid-forward."""
+    _interrupt = False

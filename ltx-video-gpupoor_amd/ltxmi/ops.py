@@ -77,13 +77,17 @@ def _rows(t):
 
 
 def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, gate_table=None, gate_temb=None,
-         rows_per_group=1, algo=0, rowsumsq=None, rowsumsq_cols=0):
+         rows_per_group=1, algo=0, rowsumsq=None, rowsumsq_cols=0, a_kblock=0, a_kblock_stride=0):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  ``a``/``out``/``residual`` may be row-strided 2-D views.
     gate_temb: 2-D view [groups, N] (row stride = gate_ld)."""
     _chk_bf16(a, w, bias, out, residual, gate_table, gate_temb)
     a2, M, lda = _rows(a)
     N, K = w.shape
-    if a2.shape[1] != K:
+    if a_kblock:
+        # ``a`` is block 0 of a K-blocked operand: [M, a_kblock] rows; block j lies j * a_kblock_stride elements further
+        if a2.shape[1] != a_kblock or K % a_kblock:
+            raise ValueError(f"ltxmi.gemm: K-blocked a must be [M, {a_kblock}] with K={K} a multiple of the block")
+    elif a2.shape[1] != K:
         raise ValueError(f"ltxmi.gemm: a is [{M},{a2.shape[1]}] but w is [{N},{K}]")
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=a.device)
@@ -106,6 +110,7 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, gate_table
         args.gate_ld = gate_temb.stride(0) if gate_temb.dim() == 2 else 0
     args.rows_per_group = rows_per_group
     args.algo = algo               # 0 = kernel chosen by shape; 128 / 256: diagnostics (include/ltxmi.h)
+    args.a_kblock, args.a_kblock_stride = a_kblock, a_kblock_stride
     if rowsumsq is not None:
         # fp32 [M, rowsumsq_cols/64]: per-64-column sums of squares of the bf16 outputs, columns < rowsumsq_cols
         if rowsumsq.dtype != torch.float32 or rowsumsq.dim() != 2 or rowsumsq.shape[0] != M or rowsumsq.stride(1) != 1 \
@@ -156,12 +161,14 @@ def attention_fuses_qnorm(B, H, Lq, Lk, dh, has_key_bias=False):
     return bool(lib.ltxmi_attention_fuses_qnorm(B, H, Lq, Lk, dh, int(has_key_bias)))
 
 
-def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None, rope=None):
+def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None, rope=None, out_segments=None):
     """q [B,Lq,H,dh], k/v [B,Lk,H,dh] (NHD; batch and token strides free, (H,dh) contiguous).
     key_bias: fp32 [B,Lk] additive (broadcast over heads and queries).
     q_norm = (rowsumsq fp32 [B*Lq, H*dh/64] from ``gemm(..., rowsumsq=)``, weight bf16 [H*dh], eps): q is the raw
     projection output and is RMS-normalised over all heads (+ rotated with rope = (cos [period, H*dh], sin, period))
-    while the kernel loads it -- only where ``attention_fuses_qnorm`` says so."""
+    while the kernel loads it -- only where ``attention_fuses_qnorm`` says so.
+    out_segments = (tokens per segment, elements between segments): ``out`` is segment 0's [B, segment, H, dh] view of a
+    buffer whose token axis is cut into such segments (the Ulysses return all-to-all's send buffer)."""
     _chk_bf16(q, k, v, out)
     B, Lq, H, dh = q.shape
     Lk = k.shape[1]
@@ -169,8 +176,12 @@ def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None,
         if t.stride(3) != 1 or t.stride(2) != dh:
             raise ValueError("ltxmi.attention: (heads, head_dim) must be contiguous")
     if out is None:
+        if out_segments is not None:
+            raise ValueError("ltxmi.attention: out_segments needs an explicit out")
         out = torch.empty((B, Lq, H, dh), dtype=BF16, device=q.device)
     a = _lib.AttnArgs()
+    if out_segments is not None:
+        a.o_segment_len, a.o_stride_segment = out_segments
     a.q, a.q_stride_b, a.q_stride_l = q.data_ptr(), q.stride(0), q.stride(1)
     a.k, a.k_stride_b, a.k_stride_l = k.data_ptr(), k.stride(0), k.stride(1)
     a.v, a.v_stride_b, a.v_stride_l = v.data_ptr(), v.stride(0), v.stride(1)
@@ -202,6 +213,24 @@ def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None,
     tok = _prof_begin(("attention", B, H, Lq, Lk, dh))
     check(lib.ltxmi_attention_fwd_bf16(ctypes.byref(a), _stream()), "ltxmi_attention_fwd_bf16")
     _prof_end(tok)
+    return out
+
+
+def qkv_norm_rope_pack(qkv, B, Nl, D, P, q_weight, k_weight, eps, cos=None, sin=None, rope_period=0, out=None):
+    """qkv [B*Nl, 3D] (row-strided) -> the Ulysses send buffer [P, Nl, B, 3, D/P]: q/k RMS-normalised over all D
+    channels (+ weight) and rotated, v copied, each channel in its destination rank's chunk (include/ltxmi.h)."""
+    _chk_bf16(qkv, q_weight, k_weight, cos, sin, out)
+    x2, rows, ld = _rows(qkv)
+    if rows != B * Nl or x2.shape[1] != 3 * D:
+        raise ValueError("ltxmi.qkv_norm_rope_pack: qkv must be [B*Nl, 3D]")
+    if out is None:
+        out = torch.empty((P, Nl, B, 3, D // P), dtype=BF16, device=qkv.device)
+    if not out.is_contiguous() or out.numel() != rows * 3 * D:
+        raise ValueError("ltxmi.qkv_norm_rope_pack: out must be a contiguous [P, Nl, B, 3, D/P] buffer")
+    ld_tab = cos.stride(0) if cos is not None else 0
+    check(lib.ltxmi_qkv_norm_rope_pack_bf16(_ptr(x2), ld, B, Nl, D, P, _ptr(q_weight), _ptr(k_weight), eps, _ptr(cos),
+                                            _ptr(sin), ld_tab, rope_period, _ptr(out), _stream()),
+          "ltxmi_qkv_norm_rope_pack_bf16")
     return out
 
 

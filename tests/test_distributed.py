@@ -1,6 +1,8 @@
 """N > 1 path on CPU: world-size-2 gloo processes exercise the Ulysses layout/collective code of
-ltxmi/distributed.py (the HIP compute is replaced by the CPU oracle's attention through the
-``attn_fn`` hook, which is the only thing that differs from the GPU run)."""
+ltxmi/distributed.py.  The layout tests replace the HIP compute by the CPU oracle's attention through the ``attn_fn``
+hook; the end-to-end tests run the PRODUCT's ``usp_dit_forward`` + ``UlyssesAttnProcessor`` + ``Transformer3DModel``
+with ``ltxmi.ops`` swapped for its CPU double (tests/cpu_ops_double.py: same argument meaning as the kernels, incl. the
+destination-major pack, the segmented attention output and the K-blocked GEMM operand the zero-copy exchange uses)."""
 import os
 import socket
 import sys
@@ -43,7 +45,7 @@ def _run(fn_name, world=2):
     procs = [ctx.Process(target=_worker, args=(r, world, port, fn_name, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=30)
     for rank, res in results:
@@ -97,6 +99,81 @@ def _case_clock(rank, world):
     assert t.item() == float(world)
 
 
+def _dit_setup(per_token):
+    """A tiny bf16 DiT of the product on the CPU (ops double installed) with full-size inputs, identical on every rank."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_ops_double
+    cpu_ops_double.install()
+    import ltxmi
+    from oracle import dit, sched
+    bf = torch.bfloat16
+    cfg = dict(dit.default_2b_config(), num_attention_heads=4, attention_head_dim=64, num_layers=3,
+               cross_attention_dim=256, caption_channels=128)
+    sd32 = {k: v.to(bf).float() for k, v in dit.init_state_dict(cfg, seed=3).items()}
+    f, h, w = 2, 3, 4
+    N, B, T = f * h * w, 3, 12
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, N, 128, generator=g).to(bf)
+    enc = torch.randn(B, T, 128, generator=g).to(bf)
+    mask = torch.ones(B, T)
+    mask[:, 8:] = 0
+    if per_token:
+        ts = torch.full((B, N), 0.7)
+        ts[:, : h * w] = 0.1                               # a conditioned first latent frame
+    else:
+        ts = torch.full((B, 1), 0.7)
+    m = ltxmi.Transformer3DModel(**cfg)
+    m.load_state_dict(sd32)
+    m = m.to(bf).eval()
+    fc = m.precompute_freqs_cis(sched.fractional_coords(f, h, w, 1, 25.0))
+    skip = m.create_skip_layer_mask(1, 3, 2, [1])
+    kw = dict(encoder_hidden_states=enc, encoder_attention_mask=mask, timestep=ts, skip_layer_mask=skip,
+              skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=(f, h, w))
+    return ltxmi, m, x, fc, kw
+
+
+def _usp_case(rank, world, per_token):
+    from ltxmi import distributed as sp
+    ltxmi, m, x, fc, kw = _dit_setup(per_token)
+    with torch.no_grad():
+        ref = m(x.clone(), freqs_cis=fc, return_dict=False, **kw)[0]                 # one rank, default processor
+        sp.enable_sequence_parallel(m)
+        out = sp.usp_dit_forward(m, x.clone(), fc, **kw)[0]                          # tokens sharded over the ranks
+    assert out.shape == ref.shape
+    err = float((out.float() - ref.float()).norm() / ref.float().norm())
+    # every op is row-wise: the two runs differ only by matmul blocking (row counts differ) before a bf16 rounding
+    assert err < 2e-3, err
+    # and the perturbed (STG) row really differs from the text row
+    assert float((out[2].float() - out[1].float()).norm()) > 1e-3
+
+
+def _case_usp_dit_forward(rank, world):
+    _usp_case(rank, world, per_token=False)
+
+
+def _case_usp_dit_forward_per_token(rank, world):
+    _usp_case(rank, world, per_token=True)
+
+
+def _case_usp_interrupt_is_collective(rank, world):
+    """ltxv_model._interrupt raised on ONE rank: every rank returns [None] (agreed once per forward), nobody is left
+    waiting in an all-to-all."""
+    from ltxmi import distributed as sp
+    ltxmi, m, x, fc, kw = _dit_setup(False)
+    sp.enable_sequence_parallel(m)
+
+    class Holder:
+        _interrupt = (rank == 1)
+
+    with torch.no_grad():
+        assert sp.usp_dit_forward(m, x.clone(), fc, ltxv_model=Holder(), **kw) == [None]
+
+        class Quiet:
+            _interrupt = False
+        out = sp.usp_dit_forward(m, x.clone(), fc, ltxv_model=Quiet(), **kw)
+    assert out[0] is not None and out[0].shape == (3, 24, 128)
+
+
 def test_ulysses_layout_world2():
     _run("_case_layout")
 
@@ -107,3 +184,15 @@ def test_ulysses_attention_equals_full_attention_world2():
 
 def test_bench_clock_protocol_world2():
     _run("_case_clock")
+
+
+def test_usp_dit_forward_world2():
+    _run("_case_usp_dit_forward")
+
+
+def test_usp_dit_forward_per_token_timesteps_world2():
+    _run("_case_usp_dit_forward_per_token")
+
+
+def test_usp_interrupt_is_collective_world2():
+    _run("_case_usp_interrupt_is_collective")

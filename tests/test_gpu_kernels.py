@@ -845,3 +845,72 @@ def test_attention_q_norm_and_rope_on_load(B, H, N, per_sample_tables):
     qr = dit.apply_rotary_emb(qn, tab)
     truth = attn_truth(qr.view(B, N, H, dh)[:, sel], v5[:, :, 1].cpu(), v5[:, :, 2].cpu())
     check(fused[:, sel], truth, what="q finished on load vs oracle")
+
+
+# ------------------------------------------------ kernels of the zero-copy Ulysses exchange, on ONE device
+# (the collectives themselves run in tests/test_distributed.py; here the layouts they carry are emulated locally)
+@pytest.mark.parametrize("B,Nl,H,P,per_sample", [(3, 624, 32, 8, False), (2, 100, 4, 2, True), (1, 33, 2, 1, False)])
+def test_qkv_norm_rope_pack(B, Nl, H, P, per_sample):
+    """q/k RMSNorm + RoPE + v, written destination-major [P][Nl][B][3][D/P]: against the two in-place passes
+    (rmsnorm_rope_, oracle-checked above) followed by the permutation the kernel fuses."""
+    from ltxmi import ops
+    D = H * 64
+    g = torch.Generator(device=DEV).manual_seed(180)
+    qkv = (torch.randn(B * Nl, 3 * D, generator=g, device=DEV) * 1.3).to(BF)
+    wq = (1.0 + 0.1 * torch.randn(D, generator=g, device=DEV)).to(BF)
+    wk = (1.0 + 0.1 * torch.randn(D, generator=g, device=DEV)).to(BF)
+    rows = B * Nl if per_sample else Nl
+    ang = torch.rand(rows, D // 2, generator=g, device=DEV) * 6.28
+    cos, sin = ang.cos().repeat_interleave(2, -1).to(BF), ang.sin().repeat_interleave(2, -1).to(BF)
+    out = ops.qkv_norm_rope_pack(qkv, B, Nl, D, P, wq, wk, 1e-5, cos, sin, rows)
+    ref = qkv.clone()
+    ops.rmsnorm_rope_(ref[:, :D], wq, 1e-5, cos, sin, rows)
+    ops.rmsnorm_rope_(ref[:, D:2 * D], wk, 1e-5, cos, sin, rows)
+    want = ref.view(B, Nl, 3, P, D // P).permute(3, 1, 0, 2, 4).contiguous()
+    assert out.shape == want.shape == (P, Nl, B, 3, D // P)
+    assert torch.equal(out[:, :, :, 2], want[:, :, :, 2])                       # v: a copy
+    # q, k: the same arithmetic in another kernel (the compiler may contract the multiply-adds differently): equal up
+    # to a last-bit rounding flip on a few elements
+    check(out, want.float(), rel_l2=1e-3, maxrel=8e-3, what="qkv_norm_rope_pack vs two passes + permute")
+    assert (out != want).float().mean() < 0.02
+
+
+@pytest.mark.parametrize("B,H,N,P", [(3, 4, 4992, 8), (2, 32, 2048, 2), (2, 2, 200, 4)])
+def test_attention_reads_token_major_and_writes_segmented(B, H, N, P):
+    """The attention kernel on the layouts of the zero-copy Ulysses exchange: q/k/v as token-major views of
+    [N][B][3][H][dh] (the all-to-all's receive buffer) and the output written into [P][B][N/P][H dh] (the return
+    exchange's send buffer, a segmented token axis) -- against the plain layouts."""
+    from ltxmi import ops
+    dh, Nl = 64, N // P
+    g = torch.Generator(device=DEV).manual_seed(190)
+    full = torch.randn(N, B, 3, H, dh, generator=g, device=DEV).to(BF)
+    q, k, v = (full[:, :, i].permute(1, 0, 2, 3) for i in range(3))             # [B, N, H, dh] views
+    want = ops.attention(q.contiguous(), k.contiguous(), v.contiguous())
+    osend = torch.full((P, B, Nl, H, dh), float("nan"), device=DEV, dtype=BF)
+    ops.attention(q, k, v, out=osend[0], out_segments=(Nl, B * Nl * H * dh))
+    got = osend.permute(1, 0, 2, 3, 4).reshape(B, N, H, dh)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("M,N,K,P,epi", [(1872, 2048, 2048, 8, "gate"), (5000, 384, 512, 2, "none"), (300, 256, 256, 4, "none")])
+def test_gemm_k_blocked_operand(M, N, K, P, epi):
+    """A = the return all-to-all's receive buffer [P][M][K/P], consumed in place (K-blocked), incl. the persistent kernel
+    and the gate + residual epilogue of to_out."""
+    from ltxmi import ops
+    g = torch.Generator(device=DEV).manual_seed(200)
+    a = (torch.randn(M, K, generator=g, device=DEV) * 0.5).to(BF)
+    w = (torch.randn(N, K, generator=g, device=DEV) * K ** -0.5).to(BF)
+    b = torch.randn(N, generator=g, device=DEV).to(BF)
+    blocked = a.view(M, P, K // P).permute(1, 0, 2).contiguous()                 # [P, M, K/P]
+    kw = {}
+    if epi == "gate":
+        res = torch.randn(M, N, generator=g, device=DEV).to(BF)
+        kw = dict(epilogue=ops.EPI_GATE_RESIDUAL, gate_table=torch.randn(N, generator=g, device=DEV).to(BF),
+                  gate_temb=torch.randn(3, N, generator=g, device=DEV).to(BF), rows_per_group=M // 3)
+        want = ops.gemm(a, w, b, residual=res.clone(), out=torch.empty_like(res), **kw)
+        got = ops.gemm(blocked[0], w, b, residual=res.clone(), out=torch.empty_like(res), a_kblock=K // P,
+                       a_kblock_stride=M * (K // P), **kw)
+    else:
+        want = ops.gemm(a, w, b)
+        got = ops.gemm(blocked[0], w, b, a_kblock=K // P, a_kblock_stride=M * (K // P))
+    assert torch.equal(got, want)
