@@ -132,7 +132,7 @@ class Attention(nn.Module):
         self.to_k = nn.Linear(self.cross_attention_dim, self.inner_dim, bias=bias)
         self.to_v = nn.Linear(self.cross_attention_dim, self.inner_dim, bias=bias)
         self.to_out = nn.ModuleList([nn.Linear(self.inner_dim, self.out_dim, bias=out_bias), nn.Dropout(dropout)])
-        self._packed = None
+        self._packs = {}
         self.set_processor(processor if processor is not None else AttnProcessor2_0())
 
     def set_processor(self, processor) -> None:                 # attention.py:575-595
@@ -141,30 +141,43 @@ class Attention(nn.Module):
     def get_processor(self, return_deprecated_lora: bool = False):
         return self.processor
 
-    # ---- packed projection weights (product-side layout; built lazily, dropped on reload)
-    def packed(self):
-        """(w_qkv [3D or D, Din], b_qkv, w_kv [2D, Dkv], b_kv) as contiguous bf16 tensors."""
-        key = (self.to_q.weight.data_ptr(), self.to_k.weight.data_ptr(), self.to_v.weight.data_ptr())
-        if self._packed is None or self._packed[0] != key:
-            def cat(mods):
+    # ---- packed projection weights (product-side layout; built lazily, rebuilt when a source changes)
+    def _pack(self, slot, mods):
+        """Contiguous [sum(out), in] weight (and bias) of ``mods``, cached per slot.  The key holds storage AND version
+        of every source tensor, so an in-place edit (a LoRA merge, ``weight.copy_``, ``+=``) rebuilds the pack just like
+        a reload does; the caches that derive from it (the per-layer text K/V) key on the pack and follow."""
+        srcs = [t for m in mods for t in (m.weight, m.bias) if t is not None]
+        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in srcs)
+        hit = self._packs.get(slot)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
                 w = torch.cat([m.weight for m in mods], dim=0).contiguous()
                 b = torch.cat([m.bias for m in mods], dim=0).contiguous() if mods[0].bias is not None else None
-                return w, b
-            with torch.no_grad():
-                if self.cross_attention_dim == self.query_dim:
-                    wqkv, bqkv = cat([self.to_q, self.to_k, self.to_v])
-                else:
-                    wqkv, bqkv = None, None
-                wkv, bkv = cat([self.to_k, self.to_v])
-            self._packed = (key, wqkv, bqkv, wkv, bkv)
-        return self._packed[1:]
+            hit = (key, w, b)
+            self._packs[slot] = hit
+        return hit[1], hit[2]
+
+    def packed_qkv(self):
+        """[to_q; to_k; to_v] -> ([3D, Din], [3D]) for self-attention (one projection GEMM)."""
+        if self.cross_attention_dim != self.query_dim:
+            raise ValueError("ltxmi.Attention.packed_qkv: query and key/value inputs differ")
+        return self._pack("qkv", [self.to_q, self.to_k, self.to_v])
+
+    def packed_kv(self):
+        """[to_k; to_v] -> ([2D, Dkv], [2D]) for cross-attention (the text keys / values in one GEMM)."""
+        return self._pack("kv", [self.to_k, self.to_v])
+
+    def invalidate_packed(self):
+        """Drop the packed copies (they are rebuilt on the next forward)."""
+        self._packs = {}
+        self.__dict__.pop("_text_kv_cache", None)
 
     def _load_from_state_dict(self, *a, **k):
-        self._packed = None
+        self.invalidate_packed()
         return super()._load_from_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        self.invalidate_packed()
         return super()._apply(fn, *a, **k)
 
     def forward(self, hidden_states, freqs_cis=None, encoder_hidden_states=None, attention_mask=None,
@@ -206,8 +219,13 @@ class AttnProcessor2_0:
         H = attn.heads
         dh = D // H
         x2 = hidden_states.reshape(B * N, -1)
-        wqkv, bqkv, wkv, bkv = attn.packed()
         is_cross = encoder_hidden_states is not None
+        # only the pack this call uses is built: self-attention never materialises [to_k; to_v], cross-attention never
+        # [to_q; to_k; to_v] (1.2 GB of HBM on the 2B model otherwise)
+        if is_cross:
+            wkv, bkv = attn.packed_kv()
+        else:
+            wqkv, bqkv = attn.packed_qkv()
         if not isinstance(attn.q_norm, RMSNorm):
             raise NotImplementedError("ltxmi.AttnProcessor2_0: qk_norm=None is not on this path")
 

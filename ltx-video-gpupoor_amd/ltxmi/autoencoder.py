@@ -116,7 +116,9 @@ class CausalConv3d(nn.Module):
 
     def packed(self, d2s=False):
         """[Cout, 27*Cin] tap-major bf16 (+ rows re-ordered (p1 p2 p3, c') for the depth-to-space store)."""
-        key = (self.conv.weight.data_ptr(), d2s)
+        # storage AND version of the sources: an in-place weight edit rebuilds the pack, as a reload does
+        wt, bs = self.conv.weight, self.conv.bias
+        key = (wt.data_ptr(), wt._version, None if bs is None else (bs.data_ptr(), bs._version), d2s)
         if self._packed is None or self._packed[0] != key:
             with torch.no_grad():
                 w = self.conv.weight.permute(0, 2, 3, 4, 1)                  # [Cout, 3,3,3, Cin]
@@ -758,6 +760,10 @@ def vae_decode(latents, vae: CausalVideoAutoencoder, is_video: bool = True, spli
     stats = None
     if vae_per_channel_normalize:
         stats = (vae.std_of_means.float().contiguous(), vae.mean_of_means.float().contiguous())
+    else:
+        sf = float(vae._config.get("scaling_factor", 1.0))
+        if sf != 1.0:                                    # un_normalize_latents: latents / scaling_factor (vae_encode.py:246)
+            latents = latents / sf
     return vae.decode(latents.to(vae.dtype), return_dict=False,
                       target_shape=(1, 3, fl * ts if is_video else 1, hl * ss, wl * ss),
                       timestep=timestep, _stats=stats)[0]

@@ -115,20 +115,27 @@ class UlyssesAttnProcessor:
         if H % P != 0:
             raise ValueError(f"heads {H} not divisible by the sequence-parallel degree {P}")
         Hl, Dp = H // P, D // P
-        wqkv, bqkv, _, _ = attn.packed()
+        wqkv, bqkv = attn.packed_qkv()
         qkv = ops.gemm(hidden_states.reshape(B * Nl, -1), wqkv, bqkv)                       # [B*Nl, 3D]
         cos, sin = freqs_cis                                   # already sliced to the local tokens
         cos2, sin2 = cos.reshape(-1, D), sin.reshape(-1, D)
+        assert attn.q_norm.eps == attn.k_norm.eps
         send = ops.qkv_norm_rope_pack(qkv, B, Nl, D, P, attn.q_norm.weight, attn.k_norm.weight, attn.q_norm.eps,
                                       cos2, sin2, cos2.shape[0])                            # [P, Nl, B, 3, Dp]
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)
+        if P > 1:
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=self.group)
+        else:
+            recv = send                    # one rank: the exchange is the identity (RCCL would copy the buffer)
         full = recv.view(P * Nl, B, 3, Hl, dh)                                              # [N, B, 3, Hl, dh]
         q, k, v = (full[:, :, i].permute(1, 0, 2, 3) for i in range(3))                     # [B, N, Hl, dh] views
         osend = torch.empty((P, B, Nl, Hl, dh), dtype=qkv.dtype, device=qkv.device)
         ops.attention(q, k, v, out=osend[0], softmax_scale=attn.scale, out_segments=(Nl, B * Nl * Dp))
-        orecv = torch.empty_like(osend)
-        dist.all_to_all_single(orecv, osend, group=self.group)                              # [P src][B*Nl][Dp]
+        if P > 1:
+            orecv = torch.empty_like(osend)
+            dist.all_to_all_single(orecv, osend, group=self.group)                          # [P src][B*Nl][Dp]
+        else:
+            orecv = osend
         host_mask = _host_mask(skip_layer_mask) if skip_layer_mask is not None else None
         if host_mask is not None and any(m != 1.0 for m in host_mask):
             # STG blends (attention.py:1127-1141) on the K-blocked layout, one head group at a time

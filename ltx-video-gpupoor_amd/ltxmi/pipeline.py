@@ -318,6 +318,8 @@ class LTXVideoPipeline:
             if latents is not None:
                 assert tuple(latents.shape) == latent_shape, \
                     f"Latents have to be of shape {latent_shape} but are {tuple(latents.shape)}."
+                assert timesteps[0] < 1.0, \
+                    "Input media_item or latents are provided, but they will be replaced with noise."    # :679-681
                 given, _ = self.patchifier.patchify(latents.to(device=device, dtype=latents_dtype))
                 noise = timesteps[0] * noise + (1 - timesteps[0]) * given
             latents = noise

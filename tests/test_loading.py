@@ -81,3 +81,32 @@ def test_vae_single_file_with_encoder(tmp_path):
     for k in sd:
         assert k in got and got[k].shape == sd[k].shape, k
     assert set(got) == set(sd)
+
+
+def test_packed_weights_follow_in_place_edits():
+    """The product-side packed copies ([to_q; to_k; to_v], [to_k; to_v], the tap-major conv weights) key on storage AND
+    version of their sources: an in-place edit (what a LoRA merge does) must rebuild them, and a self-attention module
+    never builds the cross-attention pack (nor the reverse)."""
+    import torch
+    from ltxmi.attention import Attention
+    from ltxmi.autoencoder import CausalConv3d
+    att = Attention(query_dim=128, heads=2, dim_head=64, bias=True, qk_norm="rms_norm")
+    w1, b1 = att.packed_qkv()
+    assert w1.shape == (384, 128) and torch.equal(w1[:128], att.to_q.weight) and set(att._packs) == {"qkv"}
+    assert att.packed_qkv()[0] is w1                                  # cached while nothing changes
+    with torch.no_grad():
+        att.to_k.weight.add_(1.0)                                     # in place: same storage, new version
+    w2, _ = att.packed_qkv()
+    assert w2 is not w1 and torch.equal(w2[128:256], att.to_k.weight)
+    with torch.no_grad():
+        att.to_v.bias.mul_(2.0)
+    assert torch.equal(att.packed_qkv()[1][256:], att.to_v.bias)
+    cross = Attention(query_dim=128, cross_attention_dim=128, heads=2, dim_head=64, bias=True, qk_norm="rms_norm")
+    wkv, _ = cross.packed_kv()
+    assert wkv.shape == (256, 128) and set(cross._packs) == {"kv"}
+    conv = CausalConv3d(64, 64)
+    p1, _ = conv.packed()
+    with torch.no_grad():
+        conv.conv.weight.mul_(0.5)
+    p2, _ = conv.packed()
+    assert p2 is not p1 and torch.allclose(p2.float(), p1.float() * 0.5, atol=1e-2)
