@@ -169,16 +169,24 @@ class _ChannelLayerNorm(nn.Module):            # causal_video_autoencoder.py:106
 
 
 class ResnetBlock3D(nn.Module):
-    """causal_video_autoencoder.py:1080-1258 with norm_layer="pixel_norm", inject_noise=False."""
+    """causal_video_autoencoder.py:1080-1258 with norm_layer="pixel_norm".
+    inject_noise (:1183-1195): the [H, W] noise is drawn on the host side of the kernels (``torch.randn`` on the device,
+    from ``noise_generator`` if one is set -- the reference uses the global RNG) and added as a broadcast."""
+
+    noise_generator = None      # class-wide default: the global RNG, as in the reference
 
     def __init__(self, dims, in_channels, out_channels=None, dropout=0.0, groups=32, eps=1e-6,
                  norm_layer="pixel_norm", inject_noise=False, timestep_conditioning=False,
                  spatial_padding_mode="zeros"):
         super().__init__()
-        if norm_layer != "pixel_norm" or inject_noise:
-            raise NotImplementedError("ltxmi.ResnetBlock3D: pixel_norm without noise injection only")
+        if norm_layer != "pixel_norm":
+            raise NotImplementedError("ltxmi.ResnetBlock3D: pixel_norm only")
         out_channels = in_channels if out_channels is None else out_channels
         self.in_channels, self.out_channels = in_channels, out_channels
+        self.inject_noise = inject_noise
+        if inject_noise:
+            self.per_channel_scale1 = nn.Parameter(torch.zeros((in_channels, 1, 1)))      # :1131
+            self.per_channel_scale2 = nn.Parameter(torch.zeros((in_channels, 1, 1)))      # :1160
         self.conv1 = CausalConv3d(in_channels, out_channels, 3, spatial_padding_mode=spatial_padding_mode)
         self.conv2 = CausalConv3d(out_channels, out_channels, 3, spatial_padding_mode=spatial_padding_mode)
         if in_channels != out_channels:
@@ -202,6 +210,8 @@ class ResnetBlock3D(nn.Module):
             sh1, sc1, sh2, sc2 = [t.contiguous() for t in ada.unbind(dim=1)]
         h = ops.pixelnorm_ada_silu(x, sc1, sh1, apply_silu=True)
         h = self.conv1(h, causal=causal)
+        if self.inject_noise:
+            h = h + self._spatial_noise(h, self.per_channel_scale1)
         h = ops.pixelnorm_ada_silu(h, sc2, sh2, apply_silu=True, out=h)
         if self.conv_shortcut is not None:
             s = self.norm3(x)
@@ -210,7 +220,16 @@ class ResnetBlock3D(nn.Module):
             s = ops.gemm(s.view(-1, C), w1, self.conv_shortcut.bias).view(Bx, T, H, W, self.out_channels)
         else:
             s = x
+        if self.inject_noise:
+            # conv2's noise (:1246) joins the skip tensor: conv2 + noise + skip is one sum, taken in conv2's epilogue
+            s = s + self._spatial_noise(s, self.per_channel_scale2)
         return self.conv2(h, causal=causal, add=s)            # conv2 + skip add in one epilogue
+
+    def _spatial_noise(self, like, per_channel_scale):
+        """_feed_spatial_noise (:1183-1195) in NDHWC: noise[H, W] * scale[C], broadcast over batch and frames."""
+        _, _, H, W, C = like.shape
+        noise = torch.randn((H, W), device=like.device, dtype=like.dtype, generator=self.noise_generator)
+        return noise.view(1, 1, H, W, 1) * per_channel_scale.to(like.dtype).view(1, 1, 1, 1, C)
 
 
 class UNetMidBlock3D(nn.Module):
@@ -221,7 +240,11 @@ class UNetMidBlock3D(nn.Module):
                  attention_head_dim=-1, spatial_padding_mode="zeros"):
         super().__init__()
         if attention_head_dim > 0:
-            raise NotImplementedError("ltxmi.UNetMidBlock3D: attn_res_x blocks are not on this path")
+            # The reference as shipped cannot run this block either: UNetMidBlock3D.forward hands Attention a bare
+            # tensor (:951-956) and AttnProcessor2_0 treats it as the DiT's 1-element list
+            # (``hidden_states_wrapper.clear()``, attention.py:1002-1003): AttributeError.  No behaviour to reproduce.
+            raise NotImplementedError("ltxmi.UNetMidBlock3D: attn_res_x is unreachable in the reference "
+                                      "(its own forward raises AttributeError: 'Tensor' object has no attribute 'clear')")
         self.timestep_conditioning = timestep_conditioning
         if timestep_conditioning:
             self.time_embedder = _CombinedTimestepEmbeddings(in_channels * 4)
@@ -241,21 +264,43 @@ class UNetMidBlock3D(nn.Module):
 
 
 class DepthToSpaceUpsample(nn.Module):
-    """causal_video_autoencoder.py:1023-1065 for stride (2,2,2)."""
+    """causal_video_autoencoder.py:1023-1065.  stride (2,2,2) ("compress_all", every shipped config): convolution,
+    pixel shuffle, first-frame drop and residual in ONE kernel epilogue.  (2,1,1) / (1,2,2) ("compress_time" /
+    "compress_space", :671-684, in no shipped config): the convolution kernel, then the shuffle as a layout copy."""
 
     def __init__(self, dims, in_channels, stride, residual=False, out_channels_reduction_factor=1,
                  spatial_padding_mode="zeros"):
         super().__init__()
-        if tuple(stride) != (2, 2, 2):
-            raise NotImplementedError("ltxmi.DepthToSpaceUpsample: only compress_all (2,2,2) is on this path")
         self.stride = tuple(stride)
-        self.out_channels = 8 * in_channels // out_channels_reduction_factor
+        if self.stride not in ((2, 2, 2), (2, 1, 1), (1, 2, 2)):
+            raise NotImplementedError(f"ltxmi.DepthToSpaceUpsample: stride {self.stride}")
+        prod = self.stride[0] * self.stride[1] * self.stride[2]
+        self.out_channels = prod * in_channels // out_channels_reduction_factor
         self.conv = CausalConv3d(in_channels, self.out_channels, 3, spatial_padding_mode=spatial_padding_mode)
         self.residual = residual
         self.out_channels_reduction_factor = out_channels_reduction_factor
 
+    def _shuffle(self, y):
+        """PixelShuffleND (pixel_shuffle.py:14-21) on NDHWC: channels (c p1 p2 p3) -> [B, T p1, H p2, W p3, c]."""
+        B, T, H, W, Cf = y.shape
+        p1, p2, p3 = self.stride
+        c = Cf // (p1 * p2 * p3)
+        y = y.view(B, T, H, W, c, p1, p2, p3).permute(0, 1, 5, 2, 6, 3, 7, 4)
+        return y.reshape(B, T * p1, H * p2, W * p3, c)
+
     def forward(self, x, causal: bool = True):
-        return self.conv(x, causal=causal, d2s=True, residual=x if self.residual else None)
+        if self.stride == (2, 2, 2):
+            return self.conv(x, causal=causal, d2s=True, residual=x if self.residual else None)
+        y = self._shuffle(self.conv(x, causal=causal))
+        if self.stride[0] == 2:
+            y = y[:, 1:]
+        if self.residual:
+            prod = self.stride[0] * self.stride[1] * self.stride[2]
+            x_in = self._shuffle(x).repeat(1, 1, 1, 1, prod // self.out_channels_reduction_factor)
+            if self.stride[0] == 2:
+                x_in = x_in[:, 1:]
+            y = y + x_in
+        return y.contiguous()
 
 
 class SpaceToDepthDownsample(nn.Module):
@@ -403,8 +448,18 @@ class Decoder(nn.Module):
                 blk = DepthToSpaceUpsample(dims, cin, (2, 2, 2), residual=params.get("residual", False),
                                            out_channels_reduction_factor=params.get("multiplier", 1),
                                            spatial_padding_mode=spatial_padding_mode)
+            elif name == "compress_time":                                                # :671-677
+                blk = DepthToSpaceUpsample(dims, cin, (2, 1, 1), spatial_padding_mode=spatial_padding_mode)
+            elif name == "compress_space":                                               # :678-684
+                blk = DepthToSpaceUpsample(dims, cin, (1, 2, 2), spatial_padding_mode=spatial_padding_mode)
+            elif name == "attn_res_x":
+                blk = UNetMidBlock3D(dims, cin, num_layers=params["num_layers"], norm_layer=norm_layer,
+                                     inject_noise=params.get("inject_noise", False),
+                                     timestep_conditioning=timestep_conditioning,
+                                     attention_head_dim=params["attention_head_dim"],
+                                     spatial_padding_mode=spatial_padding_mode)          # raises: see UNetMidBlock3D
             else:
-                raise NotImplementedError(f"ltxmi.Decoder: block '{name}' is not on this path")
+                raise ValueError(f"unknown layer: {name}")
             self.up_blocks.append(blk)
         self.conv_out = make_conv_nd(dims, ch, out_channels, 3, padding=1, causal=True,
                                      spatial_padding_mode=spatial_padding_mode)

@@ -716,7 +716,44 @@ def g7():
                                      T=T, grid=[2, 8, 8]))
 
 
-CASES = {"g7": g7, "g14": g14, "g13": g13, "g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
+
+@torch.no_grad()
+def g10c():
+    """The decoder block kinds the demo / OURS configs do not use (causal_video_autoencoder.py:671-684, 1183-1195):
+    compress_time (2,1,1), compress_space (1,2,2) and inject_noise ResnetBlock3Ds, through the reference's own
+    Decoder.forward.  The noise the reference draws inside _feed_spatial_noise (unseeded torch.randn of shape [H, W]) is
+    made reproducible with torch.manual_seed and recorded by drawing the same sequence again."""
+    print("G10c decoder block variants")
+    cfg = {"_class_name": "CausalVideoAutoencoder", "dims": 3, "in_channels": 3, "out_channels": 3, "latent_channels": 8,
+           "encoder_blocks": [["res_x", {"num_layers": 1}]],
+           "decoder_blocks": [["res_x", {"num_layers": 1}], ["compress_space", {}], ["res_x", {"num_layers": 2, "inject_noise": True}],
+                              ["compress_time", {}], ["res_x", {"num_layers": 1, "inject_noise": True}]],
+           "scaling_factor": 1.0, "norm_layer": "pixel_norm", "patch_size": 2, "latent_log_var": "uniform",
+           "use_quant_conv": False, "causal_decoder": False, "timestep_conditioning": True,
+           "spatial_padding_mode": "replicate", "encoder_base_channels": 8, "decoder_base_channels": 8}
+    torch.manual_seed(120)
+    vae = ref_cva.CausalVideoAutoencoder.from_config(jsonable(cfg)).eval()
+    g = torch.Generator().manual_seed(121)
+    for n, prm in vae.decoder.named_parameters():
+        if "per_channel_scale" in n:                      # zero-initialised in the reference: make the path visible
+            prm.copy_(0.3 * torch.randn(prm.shape, generator=g))
+    t = {"sd." + k: v for k, v in vae.state_dict().items() if k.startswith("decoder.")}
+    z = torch.randn(1, 8, 3, 4, 5, generator=g)
+    ts = torch.tensor([0.05])
+    t["z"], t["timestep"] = z, ts
+    # reversed order of decoder_blocks: res_x(noise, 1 layer) @ (3,4,5), compress_time -> (5,4,5), res_x(noise, 2 layers),
+    # compress_space -> (5,8,10), res_x
+    torch.manual_seed(122)
+    out = vae.decoder(z, target_shape=(1, 3, 5, 16, 20), timestep=ts)
+    torch.manual_seed(122)
+    shapes = [(4, 5)] * 2 + [(4, 5)] * 4
+    for i, shp in enumerate(shapes):
+        t[f"noise.{i}"] = torch.randn(shp)
+    t["out"] = out
+    save("g10c_decoder_variants", t, dict(cfg=cfg, noise_shapes=[list(s) for s in shapes]))
+
+
+CASES = {"g10c": g10c, "g7": g7, "g14": g14, "g13": g13, "g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
 
 
 def main():

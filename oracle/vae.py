@@ -8,7 +8,7 @@ Follows:
   Decoder.__init__/forward             ltx_video/models/autoencoders/causal_video_autoencoder.py:585-802
   UNetMidBlock3D.forward               causal_video_autoencoder.py:897-973   (no attention blocks)
   DepthToSpaceUpsample.forward         causal_video_autoencoder.py:1051-1065
-  ResnetBlock3D.forward                causal_video_autoencoder.py:1197-1258 (inject_noise=False)
+  ResnetBlock3D.forward                causal_video_autoencoder.py:1197-1258 (inject_noise: the draws are passed in)
   unpatchify                           causal_video_autoencoder.py:1282-1299
   AutoencoderKLWrapper.decode/_decode  ltx_video/models/autoencoders/vae.py:343-413 (+tiling :193-263)
   vae_decode/_run_decoder/un_normalize_latents  ltx_video/models/autoencoders/vae_encode.py:94-165,239-247
@@ -64,10 +64,17 @@ def decoder_plan(cfg):
         if isinstance(params, int):
             params = {"num_layers": params}
         if name == "res_x":
-            plan.append(dict(kind="mid", channels=cin, num_layers=params["num_layers"]))
+            plan.append(dict(kind="mid", channels=cin, num_layers=params["num_layers"],
+                             inject_noise=params.get("inject_noise", False)))
+        elif name == "attn_res_x":
+            # UNetMidBlock3D with attention blocks (:646-657): in the reference as shipped this block cannot run --
+            # UNetMidBlock3D.forward hands a bare tensor to Attention (:951-956) whose AttnProcessor2_0 treats it as the
+            # 1-element list of the DiT (``hidden_states_wrapper.clear()``, attention.py:1002-1003) and raises
+            # AttributeError: 'Tensor' object has no attribute 'clear'.  There is nothing to restate.
+            raise NotImplementedError("attn_res_x: unreachable in the reference (its own forward raises AttributeError)")
         elif name == "res_x_y":
             ch = ch // params.get("multiplier", 2)
-            plan.append(dict(kind="res", cin=cin, cout=ch))
+            plan.append(dict(kind="res", cin=cin, cout=ch, inject_noise=params.get("inject_noise", False)))
         elif name in ("compress_time", "compress_space", "compress_all"):
             stride = {"compress_time": (2, 1, 1), "compress_space": (1, 2, 2),
                       "compress_all": (2, 2, 2)}[name]
@@ -141,9 +148,15 @@ def _layer_norm_ch(x, sd, p, eps):
     return x.permute(0, 4, 1, 2, 3)
 
 
-def resnet_block(x, sd, p, causal, pad_mode, timestep_embed=None, cin=None, cout=None):
-    """ResnetBlock3D.forward with norm_layer="pixel_norm", inject_noise=False, eps=1e-6
-    (causal_video_autoencoder.py:1197-1258)."""
+def _feed_spatial_noise(h, scale, noise):
+    """ResnetBlock3D._feed_spatial_noise (:1183-1195): ``noise`` is the [H, W] draw the reference takes from
+    torch.randn there (passed in, so that oracle and product can be fed the same draw)."""
+    return h + (noise[None].to(h.dtype) * scale.to(h.dtype))[None, :, None]
+
+
+def resnet_block(x, sd, p, causal, pad_mode, timestep_embed=None, cin=None, cout=None, noise=None):
+    """ResnetBlock3D.forward with norm_layer="pixel_norm", eps=1e-6 (causal_video_autoencoder.py:1197-1258).
+    noise = (n1, n2): the two [H, W] draws of an inject_noise block, or None."""
     B = x.shape[0]
     h = pixel_norm(x)
     if timestep_embed is not None:
@@ -153,11 +166,15 @@ def resnet_block(x, sd, p, causal, pad_mode, timestep_embed=None, cin=None, cout
         h = h * (1 + scale1) + shift1
     h = F.silu(h)
     h = causal_conv3d(h, sd, p + "conv1.", causal, pad_mode)
+    if noise is not None:
+        h = _feed_spatial_noise(h, sd[p + "per_channel_scale1"], noise[0])
     h = pixel_norm(h)
     if timestep_embed is not None:
         h = h * (1 + scale2) + shift2
     h = F.silu(h)
     h = causal_conv3d(h, sd, p + "conv2.", causal, pad_mode)
+    if noise is not None:
+        h = _feed_spatial_noise(h, sd[p + "per_channel_scale2"], noise[1])
     if (p + "conv_shortcut.weight") in sd:
         x = _layer_norm_ch(x, sd, p + "norm3.", 1e-6)
         x = F.conv3d(x, sd[p + "conv_shortcut.weight"], sd[p + "conv_shortcut.bias"])
@@ -181,8 +198,16 @@ def depth_to_space_upsample(x, sd, p, blk, causal, pad_mode):
     return x
 
 
-def decoder_forward(sd, cfg, sample, timestep=None, prefix="decoder."):
-    """Decoder.forward (causal_video_autoencoder.py:735-802)."""
+def decoder_forward(sd, cfg, sample, timestep=None, prefix="decoder.", noises=None):
+    """Decoder.forward (causal_video_autoencoder.py:735-802).  ``noises``: the [H, W] draws of the inject_noise blocks
+    in the order the reference takes them (two per ResnetBlock3D: after conv1, after conv2)."""
+    noises = list(noises) if noises is not None else None
+
+    def take(blk):
+        if not blk.get("inject_noise"):
+            return None
+        return (noises.pop(0), noises.pop(0))
+
     causal = cfg.get("causal_decoder", False)
     pad_mode = cfg.get("spatial_padding_mode", "zeros")
     tcond = cfg.get("timestep_conditioning", False)
@@ -203,9 +228,9 @@ def decoder_forward(sd, cfg, sample, timestep=None, prefix="decoder."):
                     scaled_t.flatten(), sd, p + "time_embedder.", x.dtype)
                 temb = temb.view(B, temb.shape[-1], 1, 1, 1)
             for j in range(blk["num_layers"]):
-                x = resnet_block(x, sd, f"{p}res_blocks.{j}.", causal, pad_mode, temb)
+                x = resnet_block(x, sd, f"{p}res_blocks.{j}.", causal, pad_mode, temb, noise=take(blk))
         elif blk["kind"] == "res":
-            x = resnet_block(x, sd, p, causal, pad_mode, None)
+            x = resnet_block(x, sd, p, causal, pad_mode, None, noise=take(blk))
         else:
             x = depth_to_space_upsample(x, sd, p, blk, causal, pad_mode)
     x = pixel_norm(x)
@@ -262,14 +287,14 @@ def hw_tiled_decode(sd, cfg, z, timestep, tile_sample_min_size=512, overlap=0.25
 
 
 def decode(sd, cfg, z, timestep=None, use_z_tiling=False, z_sample_size=4, use_hw_tiling=False,
-           tile_sample_min_size=512):
+           tile_sample_min_size=512, noises=None):
     """AutoencoderKLWrapper.decode, vae.py:357-413 (use_quant_conv=False,
     normalize_latent_channels=False).  The z-tiled branch returns fp16 like the
-    reference (:388)."""
+    reference (:388).  ``noises``: the draws of inject_noise blocks (untiled decode only)."""
     def _dec(t):
         if use_hw_tiling:
             return hw_tiled_decode(sd, cfg, t, timestep, tile_sample_min_size)
-        return decoder_forward(sd, cfg, t, timestep)
+        return decoder_forward(sd, cfg, t, timestep, noises=noises)
 
     if use_z_tiling and z.shape[2] > (z_sample_size + 1) > 1:
         tl = z_sample_size
@@ -340,11 +365,19 @@ def init_state_dict(cfg, seed=0, dtype=torch.float32, prefix="decoder."):
             for j in range(blk["num_layers"]):
                 conv(f"{p}.res_blocks.{j}.conv1.conv", c, c)
                 conv(f"{p}.res_blocks.{j}.conv2.conv", c, c)
+                if blk.get("inject_noise"):                 # (the reference initialises these to zero)
+                    sd[f"{p}.res_blocks.{j}.per_channel_scale1"] = 0.3 * torch.randn(c, 1, 1, generator=g)
+                    sd[f"{p}.res_blocks.{j}.per_channel_scale2"] = 0.3 * torch.randn(c, 1, 1, generator=g)
                 if tcond:
                     sd[f"{p}.res_blocks.{j}.scale_shift_table"] = torch.randn(4, c, generator=g) / c ** 0.5
         elif blk["kind"] == "res":
             conv(p + ".conv1.conv", blk["cin"], blk["cout"])
             conv(p + ".conv2.conv", blk["cout"], blk["cout"])
+            if blk.get("inject_noise"):
+                # (in the reference BOTH scales have in_channels entries, :1131,1160: such a block only works with
+                # cin == cout or broadcastable sizes; kept as the reference has it)
+                sd[p + ".per_channel_scale1"] = 0.3 * torch.randn(blk["cin"], 1, 1, generator=g)
+                sd[p + ".per_channel_scale2"] = 0.3 * torch.randn(blk["cin"], 1, 1, generator=g)
             if blk["cin"] != blk["cout"]:
                 conv(p + ".conv_shortcut", blk["cin"], blk["cout"], k=1)
                 sd[p + ".norm3.norm.weight"] = 1.0 + 0.1 * torch.randn(blk["cin"], generator=g)

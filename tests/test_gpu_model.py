@@ -339,6 +339,76 @@ def test_vae_decode_bench_size_both_convolutions_agree():
     assert e < 1.5e-2 and maxrel(out, ref) < 8e-2
 
 
+def test_vae_decoder_block_variants():
+    """compress_time / compress_space upsamplers and inject_noise resnet blocks (causal_video_autoencoder.py:671-684,
+    1183-1195; in no shipped config, pinned by golden G10c) in the product's decoder against the oracle fed the same
+    noise draws (a twin of the device generator, drawn in the reference's order)."""
+    from oracle import vae as ov
+    import ltxmi
+    from ltxmi import autoencoder as ae
+    cfg = {"_class_name": "CausalVideoAutoencoder", "dims": 3, "in_channels": 3, "out_channels": 3, "latent_channels": 128,
+           "decoder_blocks": [["res_x", {"num_layers": 1}], ["compress_space", {}],
+                              ["res_x", {"num_layers": 2, "inject_noise": True}], ["compress_time", {}],
+                              ["res_x", {"num_layers": 1, "inject_noise": True}]],
+           "scaling_factor": 1.0, "norm_layer": "pixel_norm", "patch_size": 4, "latent_log_var": "uniform",
+           "use_quant_conv": False, "causal_decoder": False, "timestep_conditioning": True,
+           "spatial_padding_mode": "replicate", "decoder_base_channels": 64, "build_encoder": False}
+    raw = dict(ov.init_state_dict(cfg, seed=21))
+    sd = {k: (v.to(BF).float() if v.is_floating_point() and v.dim() > 0 else v) for k, v in raw.items()}
+    assert any("per_channel_scale1" in k for k in sd)
+    z = torch.randn(1, 128, 3, 4, 5, generator=torch.Generator().manual_seed(22)).to(BF)
+    ts = torch.tensor([0.05])
+    twin = torch.Generator(device=DEV).manual_seed(23)
+    noises = [torch.randn((4, 5), generator=twin, device=DEV, dtype=BF).float().cpu() for _ in range(6)]
+    truth = ov.vae_decode(sd, cfg, z.float(), ts, noises=noises)
+    sdb = {k: (v.to(BF) if v.is_floating_point() and v.dim() > 0 else v) for k, v in sd.items()}
+    eager = ov.vae_decode(sdb, cfg, z, ts, noises=[n.to(BF) for n in noises])
+    v = build_vae(cfg, sd)
+    old = ae.ResnetBlock3D.noise_generator
+    try:
+        ae.ResnetBlock3D.noise_generator = torch.Generator(device=DEV).manual_seed(23)
+        out = ltxmi.vae_decode(z.to(DEV), v, True, vae_per_channel_normalize=True, timestep=ts.to(DEV))
+    finally:
+        ae.ResnetBlock3D.noise_generator = old
+    assert out.shape == truth.shape == (1, 3, 5, 32, 40)
+    assert_parity(out, truth, eager, "decoder block variants (compress_time / compress_space / inject_noise)")
+    with pytest.raises(NotImplementedError, match="unreachable in the reference"):
+        ltxmi.CausalVideoAutoencoder.from_config(dict(cfg, decoder_blocks=[["attn_res_x", {"num_layers": 1, "attention_head_dim": 32}]]))
+
+
+def test_checkpoint_loaded_from_disk_runs_the_oracles_forward(tmp_path):
+    """f4 on the device: a single-file safetensors checkpoint with the reference's key prefixes and the config blob in
+    its metadata (transformer3d.py:271-326, causal_video_autoencoder.py:35-120), written to disk, loaded with
+    from_pretrained and RUN -- DiT forward and VAE decode against the oracle on the same weights."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from oracle import dit, vae as ov
+    import ltxmi
+    grid, B, T = (2, 4, 6), 2, 24
+    cfg, sd32, x, enc, mask, ts, frac = dit_case(2, 64, 2, grid, B, T, seed=31)
+    vcfg, vsd = vae_case("b")
+    blob = {"model.diffusion_model." + k: v.to(BF) for k, v in sd32.items()}
+    blob.update({"vae." + k: (v.to(BF) if v.is_floating_point() and v.dim() > 0 else v) for k, v in vsd.items()})
+    path = os.path.join(tmp_path, "ltxv.safetensors")
+    save_file(blob, path, metadata={"config": json.dumps({"transformer": cfg, "vae": vcfg})})
+    m = ltxmi.Transformer3DModel.from_pretrained(path, device=DEV).eval()
+    truth, eager = run_oracles(cfg, sd32, x, enc, mask, ts, frac, grid)
+    fc = m.precompute_freqs_cis(frac.to(DEV))
+    out = m(x.to(DEV), freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV),
+            timestep=ts.to(DEV), latent_shape=grid, ltxv_model=_Holder(), return_dict=False)[0]
+    assert_parity(out, truth, eager, "DiT loaded from a single-file checkpoint")
+    v = ltxmi.CausalVideoAutoencoder.from_pretrained(path, device=DEV).eval()
+    if vcfg.get("timestep_conditioning"):
+        v.decoder.timestep_scale_multiplier.data = v.decoder.timestep_scale_multiplier.data.float()
+    z = torch.randn(1, 128, 2, 3, 4, generator=torch.Generator().manual_seed(32)).to(BF)
+    t05 = torch.tensor([0.05])
+    vtruth = ov.vae_decode(vsd, vcfg, z.float(), t05)
+    veager = ov.vae_decode({k: (a.to(BF) if a.is_floating_point() and a.dim() > 0 else a) for k, a in vsd.items()}, vcfg, z, t05)
+    vout = ltxmi.vae_decode(z.to(DEV), v, True, vae_per_channel_normalize=True, timestep=t05.to(DEV))
+    assert_parity(vout, vtruth, veager, "VAE loaded from a single-file checkpoint")
+
+
 def test_vae_tiled_decode_matches_oracle_tiling():
     from oracle import vae as ov
     cfg, sd = vae_case("b", base=64)

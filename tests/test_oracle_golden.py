@@ -401,3 +401,17 @@ def test_g11_config1_loop(golden):
         lat = sched.denoising_step(ts, lat, v, tt.expand(1).unsqueeze(-1), None, tt)
         torch.testing.assert_close(lat, t[f"latents_out.{i}"], rtol=2e-5, atol=5e-6)
     torch.testing.assert_close(sched.unpatchify(lat, f, h, w), t["out_latents"], rtol=2e-5, atol=5e-6)
+
+
+def test_g10c_decoder_block_variants(golden):
+    """compress_time / compress_space upsamplers and inject_noise resnet blocks through the reference's own
+    Decoder.forward (causal_video_autoencoder.py:671-684, 1183-1195, 1230, 1246), with the recorded noise draws."""
+    t, meta = golden("g10c_decoder_variants")
+    cfg = meta["cfg"]
+    sd = sub(t, "sd.")
+    noises = [t[f"noise.{i}"] for i in range(len(meta["noise_shapes"]))]
+    out = vae.decoder_forward(sd, cfg, t["z"], t["timestep"], noises=noises)
+    torch.testing.assert_close(out, t["out"], **TOL)
+    # the noise really acts
+    quiet = vae.decoder_forward(sd, cfg, t["z"], t["timestep"], noises=[torch.zeros_like(n) for n in noises])
+    assert (quiet - t["out"]).abs().max() > 1e-3
