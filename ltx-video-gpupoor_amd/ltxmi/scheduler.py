@@ -96,11 +96,16 @@ class RectifiedFlowScheduler:
         lower = [x for x in self.host_timesteps + [0.0] if x < t - t_eps]
         return t - lower[0]
 
+    def add_noise(self, original_samples, noise, timesteps):                         # rf.py:382-392
+        sigmas = timesteps
+        while sigmas.ndim < original_samples.ndim:
+            sigmas = sigmas[..., None]
+        return (1 - sigmas) * original_samples + sigmas * noise
+
     def step(self, model_output, timestep, sample, return_dict=True, stochastic_sampling=False, **kwargs):   # rf.py:311-380
+        """``generator`` (extension): the RNG of the stochastic branch's noise (the reference uses the global one)."""
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
-        if stochastic_sampling:
-            raise NotImplementedError("stochastic sampling is not on this path")
         t_eps = 1e-6
         padded = torch.cat([self.timesteps, torch.zeros(1, device=self.timesteps.device)])
         if timestep.ndim == 0:
@@ -111,7 +116,12 @@ class RectifiedFlowScheduler:
             mask = padded[:, None, None] < timestep[None] - t_eps
             lower, _ = (mask * padded[:, None, None]).max(dim=0)
             dt = (timestep - lower)[..., None]
-        prev = sample - dt * model_output
+        if stochastic_sampling:                                                       # rf.py:368-373
+            x0 = sample - timestep[..., None] * model_output
+            noise = torch.randn(sample.shape, device=sample.device, dtype=sample.dtype, generator=kwargs.get("generator"))
+            prev = self.add_noise(x0, noise, timestep[..., None] - dt)
+        else:
+            prev = sample - dt * model_output
         if not return_dict:
             return (prev,)
         return RectifiedFlowSchedulerOutput(prev_sample=prev)

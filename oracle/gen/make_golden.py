@@ -229,6 +229,13 @@ def g6():
     tok[:, 12:16] = 0.31
     t["step.tok_t"] = tok
     t["step.per_token"] = s.step(v, tok, sample, return_dict=False)[0]
+    # stochastic sampling (rf.py:368-373): x0 = x - t v, re-noised to the next timestep with torch.randn_like(sample)
+    # (unseeded in the reference: made reproducible with manual_seed and recorded by drawing it again)
+    for name, tt in (("global", s.timesteps[2][None, None].expand(1, 24).clone()), ("per_token", tok)):
+        torch.manual_seed(7)
+        t[f"step.stochastic_{name}"] = s.step(v, tt, sample, return_dict=False, stochastic_sampling=True)[0]
+        torch.manual_seed(7)
+        t[f"step.stochastic_{name}_noise"] = torch.randn_like(sample)
     save("g6_scheduler", t, dict(shapes={k: list(v) for k, v in shapes.items()}))
 
 

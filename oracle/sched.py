@@ -39,8 +39,9 @@ def set_timesteps(num_inference_steps, samples_shape, shifting="SD3", target_shi
     return ts
 
 
-def scheduler_step(timesteps, model_output, timestep, sample):
-    """RectifiedFlowScheduler.step, stochastic_sampling=False, rf.py:344-380."""
+def scheduler_step(timesteps, model_output, timestep, sample, stochastic_noise=None):
+    """RectifiedFlowScheduler.step, rf.py:344-380.  ``stochastic_noise``: the torch.randn_like(sample) draw of the
+    stochastic_sampling branch (:368-373, per-token timestep form), or None for the deterministic Euler step."""
     t_eps = 1e-6
     padded = torch.cat([timesteps, torch.zeros(1)])
     if timestep.ndim == 0:
@@ -51,6 +52,10 @@ def scheduler_step(timesteps, model_output, timestep, sample):
         mask = padded[:, None, None] < timestep[None] - t_eps
         lower, _ = (mask * padded[:, None, None]).max(dim=0)
         dt = (timestep - lower)[..., None]
+    if stochastic_noise is not None:
+        x0 = sample - timestep[..., None] * model_output
+        sigma = timestep[..., None] - dt                                   # add_noise (:382-392): alphas = 1 - sigmas
+        return (1 - sigma) * x0 + sigma * stochastic_noise
     return sample - dt * model_output
 
 

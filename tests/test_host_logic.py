@@ -75,3 +75,20 @@ def test_g7_product_guidance_tables_and_skip_masks(golden):
     ogs, ostg, ors, oskips, *_ = pc.guidance_tables(ts, kw["guidance_scale"], kw["stg_scale"], kw["rescaling_scale"],
                                                     kw["skip_block_list"], guidance_timesteps=kw["guidance_timesteps"])
     assert (gs, stg, rs, skips) == (ogs, ostg, ors, oskips)
+
+
+def test_g6_product_scheduler_step(golden):
+    """ltxmi.RectifiedFlowScheduler.step: Euler (global and per-token timesteps) and the stochastic branch (same torch
+    generator state as the recorded draw) against G6."""
+    t, meta = golden("g6_scheduler")
+    s = ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1)
+    s.set_timesteps(8, samples_shape=tuple(meta["shapes"]["small"]), device="cpu")
+    ts = s.timesteps.float()
+    torch.testing.assert_close(ts, t["step.timesteps"], rtol=1e-6, atol=1e-7)
+    out = s.step(t["step.v"], ts[2], t["step.sample"], return_dict=False)[0]
+    torch.testing.assert_close(out, t["step.global"], **TOL)
+    out = s.step(t["step.v"], t["step.tok_t"], t["step.sample"], return_dict=False)[0]
+    torch.testing.assert_close(out, t["step.per_token"], **TOL)
+    g = torch.Generator().manual_seed(7)            # the draw the reference took from the global RNG seeded with 7
+    out = s.step(t["step.v"], t["step.tok_t"], t["step.sample"], return_dict=False, stochastic_sampling=True, generator=g)[0]
+    torch.testing.assert_close(out, t["step.stochastic_per_token"], **TOL)

@@ -415,3 +415,12 @@ def test_g10c_decoder_block_variants(golden):
     # the noise really acts
     quiet = vae.decoder_forward(sd, cfg, t["z"], t["timestep"], noises=[torch.zeros_like(n) for n in noises])
     assert (quiet - t["out"]).abs().max() > 1e-3
+
+
+def test_g6_scheduler_stochastic_step(golden):
+    """RectifiedFlowScheduler.step(stochastic_sampling=True) (rf.py:368-373) with the recorded noise draw."""
+    t, _ = golden("g6_scheduler")
+    tsched = t["step.timesteps"]
+    for name, tt in (("global", tsched[2][None, None].expand(1, 24)), ("per_token", t["step.tok_t"])):
+        out = sched.scheduler_step(tsched, t["step.v"], tt, t["step.sample"], stochastic_noise=t[f"step.stochastic_{name}_noise"])
+        torch.testing.assert_close(out, t[f"step.stochastic_{name}"], **TOL)
