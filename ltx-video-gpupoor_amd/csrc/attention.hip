@@ -35,13 +35,7 @@ constexpr int KV_TILE = 64;
 constexpr int Q_PER_WAVE = 32;
 constexpr int Q_PER_WG = 128;
 constexpr float LOG2E = 1.4426950408889634f;
-#ifndef LTXMI_ATTN_PIPE
-#define LTXMI_ATTN_PIPE 1
-#endif
-#ifndef LTXMI_ATTN_QB
-#define LTXMI_ATTN_QB 2
-#endif
-constexpr int ATTN_QB_BIG = LTXMI_ATTN_QB;
+constexpr int ATTN_QB_BIG = 2;        // 32-row query blocks per wave when the grid still fills the chip
 
 template <int DH>
 struct AttnCfg {
@@ -59,12 +53,6 @@ struct AttnCfg {
     }
 };
 
-#ifndef LTXMI_ATTN_MAXTREE
-#define LTXMI_ATTN_MAXTREE 1
-#endif
-#ifndef LTXMI_ATTN_ONES
-#define LTXMI_ATTN_ONES 1      // 1: row sums on the matrix pipe (masked all-ones A operand) instead of v_add
-#endif
 
 // QB = 32-row query blocks per wave (1 or 2).  With QB = 2 a wave owns 64 query rows; the two
 // blocks are independent softmax streams that share every K / V^T fragment read, and the source
@@ -189,7 +177,6 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
 
     f32x16 oT[QB][C::DBLK];
     float m_run[QB];           // running max: raw scores (no bias) or scaled+biased log2 domain (bias)
-#if LTXMI_ATTN_ONES
     // Row sums on the matrix pipe (the VALU is the co-limiting pipe at head_dim 64): the P^T fragment
     // of the 32x32x16 PV product, re-read as the B operand of a 16x16x32 MFMA, puts query (l & 15)
     // [+16 for odd 16-lane groups] on the column and this lane's 8 keys in k-group (l >> 4).  With
@@ -203,9 +190,6 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
 #pragma unroll
         for (int e = 0; e < 8; ++e) ones[e] = on ? (__bf16)1.0f : (__bf16)0.0f;
     }
-#else
-    float l_run[QB];           // this lane's half of the running row sum
-#endif
     bf16x8 kaug, maug[QB];      // FOLD: A operand (ones at k = 0, 1) and B operand (-m as hi + lo bf16)
 #pragma unroll
     for (int e = 0; e < 8; ++e) kaug[e] = (hh == 0 && e < 2) ? (__bf16)1.0f : (__bf16)0.0f;
@@ -214,11 +198,7 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
         m_run[i] = FOLD ? 0.f : -INFINITY;
 #pragma unroll
         for (int e = 0; e < 8; ++e) maug[i][e] = (__bf16)0.0f;
-#if LTXMI_ATTN_ONES
         lT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#else
-        l_run[i] = 0.f;
-#endif
 #pragma unroll
         for (int d = 0; d < C::DBLK; ++d)
 #pragma unroll
@@ -276,7 +256,6 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
                         if (key >= p.Lk) sT[i][kb][e] = -INFINITY;
                     }
             }
-#if LTXMI_ATTN_MAXTREE
             // row max as a shallow tree (depth 4 with v_max3_f32) instead of one 32-deep dependent
             // chain.  Built with -fno-honor-nans (attention.o only): without it hipcc puts a
             // canonicalising v_max in front of every MFMA output that feeds fmaxf.
@@ -293,13 +272,6 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
                 const float a = max3(l1[1], l1[2], l1[3]), b2 = max3(l1[4], l1[5], l1[6]), c2 = max3(l1[7], l1[8], l1[9]);
                 mt = fmaxf(max3(a, b2, c2), l1[10]);
             }
-#else
-            float mt = sT[i][0][0];
-#pragma unroll
-            for (int e = 1; e < 16; ++e) mt = fmaxf(mt, sT[i][0][e]);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mt = fmaxf(mt, sT[i][1][e]);
-#endif
             {
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
                 mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -319,12 +291,8 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
                         for (int e = 0; e < 16; ++e) sT[i][kb][e] -= dq;
                     if (!first) {
                         const float alpha = fast_exp2(-dq);
-#if LTXMI_ATTN_ONES
                         lT[i][0] *= alpha;
                         lT[i][1] *= __shfl(alpha, (lane + 16) & 63, 64);
-#else
-                        l_run[i] *= alpha;
-#endif
 #pragma unroll
                         for (int d = 0; d < C::DBLK; ++d)
 #pragma unroll
@@ -344,13 +312,9 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
                 if (__any(m_new != m_run[i])) {
                     asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
                     const float alpha = HAS_BIAS ? fast_exp2(m_run[i] - m_new) : fast_exp2((m_run[i] - m_new) * c);
-#if LTXMI_ATTN_ONES
                     // lane n (< 16) holds the sums of queries n (reg 0) and n + 16 (reg 1)
                     lT[i][0] *= alpha;
                     lT[i][1] *= __shfl(alpha, (lane + 16) & 63, 64);
-#else
-                    l_run[i] *= alpha;
-#endif
 #pragma unroll
                     for (int d = 0; d < C::DBLK; ++d)
 #pragma unroll
@@ -362,33 +326,22 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
 
             // ---------------- P = exp2(x - m), bf16 fragments
             bf16x8 pf[4];
-#if !LTXMI_ATTN_ONES
-            float lsum = 0.f;
-#endif
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     sT[i][kb][e] = fast_exp2(FOLD ? sT[i][kb][e] : (HAS_BIAS ? sT[i][kb][e] + nmoff : __builtin_fmaf(sT[i][kb][e], c, nmoff)));
-#if !LTXMI_ATTN_ONES
-                    lsum += sT[i][kb][e];
-#endif
                 }
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pf[2 * kb + h2][e] = (__bf16)sT[i][kb][8 * h2 + e];
             }
-#if !LTXMI_ATTN_ONES
-            l_run[i] += lsum;
-#endif
 
             // ---------------- O^T += V^T P^T  (;  l += ones . P^T)
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp) {
-#if LTXMI_ATTN_ONES
                 lT[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[sp], lT[i], 0, 0, 0);
-#endif
 #pragma unroll
                 for (int d = 0; d < C::DBLK; ++d) {
                     const char* base = s + v_rd + (2 * sp * C::DBLK + d) * 512;
@@ -427,14 +380,9 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
     // ---------------- epilogue: O = O^T / l
 #pragma unroll
     for (int i = 0; i < QB; ++i) {
-#if LTXMI_ATTN_ONES
         // query r's sum sits in lane (r & 15), register (r >> 4)
         const float l0 = __shfl(lT[i][0], r & 15, 64), l1 = __shfl(lT[i][1], r & 15, 64);
         const float l = (r & 16) ? l1 : l0;
-#else
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[i]), __float_as_uint(l_run[i]), false, false);
-        const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-#endif
         const float inv = 1.0f / l;
         // A lane holds 8-byte pieces of ONE output row; stored from registers, every store instruction
         // would touch 32 different 128-byte lines with 16 bytes each (store-issue bound, cdna guide T21).
@@ -512,7 +460,7 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     p.o_seg = a->o_segment_len; p.o_sseg = a->o_stride_segment;
     LTXMI_REQUIRE(a->o_segment_len >= 0 && a->o_stride_segment % 8 == 0, LTXMI_ERR_INVALID_ARG,
                   "ltxmi_attention_fwd_bf16: bad output segment geometry");
-    const bool pipe_ok = LTXMI_ATTN_PIPE && attn_pipe_takes(a->B, a->H, a->Lq, a->Lk, a->head_dim, a->key_bias != nullptr);
+    const bool pipe_ok = attn_pipe_takes(a->B, a->H, a->Lq, a->Lk, a->head_dim, a->key_bias != nullptr);
     if (a->q_rowsumsq) {
         LTXMI_REQUIRE(pipe_ok, LTXMI_ERR_UNSUPPORTED,
                       "ltxmi_attention_fwd_bf16: q normalisation on load is not available for this shape "
@@ -546,5 +494,5 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
 }
 
 extern "C" int ltxmi_attention_fuses_qnorm(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias) {
-    return (LTXMI_ATTN_PIPE && attn_pipe_takes(B, H, Lq, Lk, head_dim, has_key_bias != 0)) ? 1 : 0;
+    return (attn_pipe_takes(B, H, Lq, Lk, head_dim, has_key_bias != 0)) ? 1 : 0;
 }

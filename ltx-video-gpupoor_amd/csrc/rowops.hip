@@ -353,7 +353,7 @@ extern "C" int ltxmi_norm_modulate_bf16(const void* x, int64_t ldx, void* y, int
     LTXMI_REQUIRE(rows > 0 && D > 0 && rows_per_group > 0, LTXMI_ERR_INVALID_ARG,
                   "ltxmi_norm_modulate_bf16: non-positive size rows=%d D=%d", rows, D);
     LTXMI_REQUIRE(D % 8 == 0 && D <= 8192 && ldx % 8 == 0 && ldy % 8 == 0 && temb_ld % 8 == 0, LTXMI_ERR_UNSUPPORTED,
-                  "ltxmi_norm_modulate_bf16: D=%d must be a multiple of 8 and <= 8192 (strides % 8 == 0)", D);
+                  "ltxmi_norm_modulate_bf16: D=%d must be a multiple of 8 and <= 8192 (strides multiples of 8)", D);
     LTXMI_REQUIRE(kind == LTXMI_NORM_RMS || kind == LTXMI_NORM_LAYER, LTXMI_ERR_INVALID_ARG,
                   "ltxmi_norm_modulate_bf16: bad kind %d", kind);
     const int grid = (rows + ROWS_PER_WG - 1) / ROWS_PER_WG;
