@@ -143,7 +143,7 @@ typedef struct ltxmi_attn_args {
      * are the projection GEMM's per-64-column sums of squares of that row (ltxmi_gemm_args.rowsumsq).  The kernel
      * applies x * rsqrt(mean(x^2) + q_norm_eps) * q_norm_weight[c] and, if rope_cos/rope_sin are given, the
      * interleaved-pair rotation with table row b * rope_stride_b + l * rope_stride_l (strides in elements; stride_b = 0:
-     * one table shared by the batch) while it loads Q.  Only where ltxmi_attention_fuses_qnorm() says 1; NULL = off. */
+     * one table shared by the batch) while it loads Q.  NULL = off. */
     const float* q_rowsumsq; int64_t q_rowsumsq_stride_b, q_rowsumsq_stride_l; int32_t q_rowsumsq_blocks;
     const void*  q_norm_weight; float q_norm_eps;
     const void*  rope_cos; const void* rope_sin; int64_t rope_stride_b, rope_stride_l;
@@ -154,8 +154,8 @@ typedef struct ltxmi_attn_args {
 } ltxmi_attn_args;
 
 int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* args, void* stream);
-/* 1 if ltxmi_attention_fwd_bf16 can normalise + rotate q on load for this shape (large head_dim-64 self-attention
- * without a key bias), else 0: the caller then runs ltxmi_rmsnorm_rope_bf16 on q as a pass of its own. */
+/* 1 if ltxmi_attention_fwd_bf16 can normalise + rotate q on load for this shape, else 0 (the caller then runs
+ * ltxmi_rmsnorm_rope_bf16 on q as a pass of its own).  Since 0.2 every shape the entry point accepts qualifies. */
 int ltxmi_attention_fuses_qnorm(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias);
 
 /* Ulysses send buffer in one pass (sequence-parallel self-attention, xdit_context_parallel.py:149-184 of the reference

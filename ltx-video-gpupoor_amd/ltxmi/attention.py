@@ -259,7 +259,11 @@ class AttnProcessor2_0:
             v3 = qkv.view(B, N, 3 * D)[:, :, 2 * D:]
         else:
             Bk, Lk, _ = encoder_hidden_states.shape
-            q2 = ops.gemm(x2, attn.to_q.weight, attn.to_q.bias)                    # [B*N, D]
+            # q's RMSNorm is applied by the attention kernel while it loads q (as in self-attention): the projection
+            # emits the per-row sums of squares, q gets no pass of its own
+            fuse_q = D % 64 == 0 and bool(ops.attention_fuses_qnorm(B, H, N, Lk, dh, attention_mask is not None))
+            ss = torch.empty((B * N, D // 64), dtype=torch.float32, device=x2.device) if fuse_q else None
+            q2 = ops.gemm(x2, attn.to_q.weight, attn.to_q.bias, rowsumsq=ss, rowsumsq_cols=D if fuse_q else 0)   # [B*N, D]
             # The text keys/values depend on the prompt and this layer's weights only: within a generation
             # they are the same at every denoise step, so they are projected + normalised once and reused
             # (same kernels on the same inputs: identical values).  Keyed on storage + version of the inputs;
@@ -278,7 +282,10 @@ class AttnProcessor2_0:
                     cache[key] = (kv, ehs, wkv)
             else:
                 kv = hit[0]
-            ops.rmsnorm_rope_(q2, attn.q_norm.weight, attn.q_norm.eps)
+            if fuse_q:
+                q_fused = ((ss, attn.q_norm.weight, attn.q_norm.eps), None)
+            else:
+                ops.rmsnorm_rope_(q2, attn.q_norm.weight, attn.q_norm.eps)
             q4 = q2.view(B, N, H, dh)
             k4 = kv.view(Bk, Lk, 2, H, dh)[:, :, 0]
             v4 = kv.view(Bk, Lk, 2, H, dh)[:, :, 1]

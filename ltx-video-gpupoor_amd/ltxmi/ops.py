@@ -157,7 +157,7 @@ def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, rope_period=0):
 
 
 def attention_fuses_qnorm(B, H, Lq, Lk, dh, has_key_bias=False):
-    """Whether ``attention(..., q_norm=...)`` is available for this shape (large head_dim-64 self-attention)."""
+    """Whether ``attention(..., q_norm=...)`` is available for this shape (every shape ``attention`` accepts)."""
     return bool(lib.ltxmi_attention_fuses_qnorm(B, H, Lq, Lk, dh, int(has_key_bias)))
 
 
@@ -166,7 +166,7 @@ def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None,
     key_bias: fp32 [B,Lk] additive (broadcast over heads and queries).
     q_norm = (rowsumsq fp32 [B*Lq, H*dh/64] from ``gemm(..., rowsumsq=)``, weight bf16 [H*dh], eps): q is the raw
     projection output and is RMS-normalised over all heads (+ rotated with rope = (cos [period, H*dh], sin, period))
-    while the kernel loads it -- only where ``attention_fuses_qnorm`` says so.
+    while the kernel loads it.
     out_segments = (tokens per segment, elements between segments): ``out`` is segment 0's [B, segment, H, dh] view of a
     buffer whose token axis is cut into such segments (the Ulysses return all-to-all's send buffer)."""
     _chk_bf16(q, k, v, out)

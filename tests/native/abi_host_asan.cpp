@@ -96,13 +96,13 @@ int main() {
     a.q_rowsumsq_blocks = 32; a.q_rowsumsq_stride_l = 32; a.q_rowsumsq_stride_b = 4992 * 32;
     a.rope_cos = p; a.rope_sin = p; a.rope_stride_l = 2048;
     expect_fail(ltxmi_attention_fwd_bf16(&a, nullptr), "attention(fused q norm, no device)");
-    a.Lq = a.Lk = 100;                                          // a shape the fusing kernel does not take
-    expect_fail(ltxmi_attention_fwd_bf16(&a, nullptr), "attention(fused q norm on a small shape)");
+    a.Lq = a.Lk = 100;                                          // the generic kernel
+    expect_fail(ltxmi_attention_fwd_bf16(&a, nullptr), "attention(fused q norm on a small shape, no device)");
     a.q_rowsumsq = nullptr; a.q_norm_weight = nullptr; a.rope_cos = a.rope_sin = nullptr;
     a.Lq = a.Lk = 4992; a.o_segment_len = 1000;                 // does not divide Lq
     expect_fail(ltxmi_attention_fwd_bf16(&a, nullptr), "attention(o segments not dividing Lq)");
-    if (ltxmi_attention_fuses_qnorm(3, 32, 4992, 4992, 64, 0) != 1 || ltxmi_attention_fuses_qnorm(1, 32, 64, 64, 64, 0) != 0 ||
-        ltxmi_attention_fuses_qnorm(3, 32, 4992, 4992, 64, 1) != 0 || ltxmi_attention_fuses_qnorm(3, 12, 4992, 4992, 128, 0) != 0) {
+    if (ltxmi_attention_fuses_qnorm(3, 32, 4992, 4992, 64, 0) != 1 || ltxmi_attention_fuses_qnorm(1, 32, 64, 64, 64, 1) != 1 ||
+        ltxmi_attention_fuses_qnorm(3, 12, 4992, 4992, 128, 0) != 1 || ltxmi_attention_fuses_qnorm(3, 12, 4992, 4992, 96, 0) != 0) {
         fprintf(stderr, "ltxmi_attention_fuses_qnorm\n");
         ++g_bad;
     }

@@ -847,6 +847,38 @@ def test_attention_q_norm_and_rope_on_load(B, H, N, per_sample_tables):
     check(fused[:, sel], truth, what="q finished on load vs oracle")
 
 
+@pytest.mark.parametrize("B,H,dh,Lq,Lk,bias,rope", [(3, 32, 64, 4992, 256, True, False),     # the DiT's cross-attention
+                                                    (2, 4, 64, 300, 77, True, False), (1, 2, 64, 100, 100, False, True),
+                                                    (1, 12, 128, 520, 520, False, True), (2, 3, 128, 130, 64, True, False)])
+def test_attention_q_norm_on_load_generic_kernel(B, H, dh, Lq, Lk, bias, rope):
+    """The same fusion in the kernel that takes everything else (key bias, small shapes, head_dim 128 incl. its
+    scale-folded form): against the two-pass form."""
+    from ltxmi import ops
+    D = H * dh
+    assert ops.attention_fuses_qnorm(B, H, Lq, Lk, dh, bias)
+    g = torch.Generator(device=DEV).manual_seed(171)
+    q = (torch.randn(B * Lq, D, generator=g, device=DEV) * 1.7).to(BF)
+    k = torch.randn(B, Lk, H, dh, generator=g, device=DEV).to(BF)
+    v = torch.randn(B, Lk, H, dh, generator=g, device=DEV).to(BF)
+    wq = (1.0 + 0.1 * torch.randn(D, generator=g, device=DEV)).to(BF)
+    kb = None
+    if bias:
+        kb = torch.zeros(B, Lk, device=DEV)
+        kb[:, Lk - Lk // 3:] = -10000.0
+    cos = sin = None
+    if rope:
+        ang = torch.rand(Lq, D // 2, generator=g, device=DEV) * 6.28
+        cos = ang.cos().repeat_interleave(2, dim=-1).to(BF)
+        sin = ang.sin().repeat_interleave(2, dim=-1).to(BF)
+    ss = q.float().reshape(B * Lq, D // 64, 64).pow(2).sum(-1).contiguous()
+    ref = q.clone()
+    ops.rmsnorm_rope_(ref, wq, 1e-6, cos, sin, Lq if rope else 0)
+    two_pass = ops.attention(ref.view(B, Lq, H, dh), k, v, key_bias=kb)
+    fused = ops.attention(q.view(B, Lq, H, dh), k, v, key_bias=kb, q_norm=(ss, wq, 1e-6),
+                          rope=(cos, sin, Lq) if rope else None)
+    check(fused, two_pass.float(), rel_l2=2e-3, maxrel=1.6e-2, what="q finished on load (generic kernel) vs two passes")
+
+
 # ------------------------------------------------ kernels of the zero-copy Ulysses exchange, on ONE device
 # (the collectives themselves run in tests/test_distributed.py; here the layouts they carry are emulated locally)
 @pytest.mark.parametrize("B,Nl,H,P,per_sample", [(3, 624, 32, 8, False), (2, 100, 4, 2, True), (1, 33, 2, 1, False)])

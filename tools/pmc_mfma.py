@@ -13,7 +13,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.match(r"(?:void )?(ltxmi::\w+(?:<[^>]*>)?)", name)
+    m = re.match(r"(?:void )?(ltxmi::(?:\w+::)*\w+(?:<[^>]*>)?)", name)
     return m.group(1) if m else None
 
 
@@ -36,7 +36,7 @@ def main():
                      mean.get("SQ_WAIT_INST_ANY", 0.0) / wave))
     rows.sort(reverse=True)
     with open(sys.argv[2], "w") as f:
-        f.write("# Matrix-pipe utilisation per kernel from PMC counters (round 1, final kernels)\n\n"
+        f.write("# Matrix-pipe utilisation per kernel from PMC counters \n\n"
                 "`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
                 "GRBM_GUI_ACTIVE -- python bench.py --steps 1 --warmup 1 --no-extras`; formulas in tools/pmc_mfma.py. "
                 "mfma busy = share of SIMD cycles with the matrix pipe executing (at the clock the chip held).\n\n"

@@ -3,7 +3,7 @@
 prescribes) into per-launch HBM traffic per kernel.  gfx950 corrections (MI355X_MICROARCH.md, HBM):
 FETCH_SIZE is reported in KiB and counts 64 B per 128-B request on wide coalesced reads -> x2;
 WRITE_SIZE in KiB is exact for streaming stores.
-Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <out.md>"""
+Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <out.md> [name of the committed .md]"""
 import csv
 import json
 import re
@@ -12,7 +12,7 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.match(r"(?:void )?(ltxmi::\w+(?:<[^>]*>)?)", name)
+    m = re.match(r"(?:void )?(ltxmi::(?:\w+::)*\w+(?:<[^>]*>)?)", name)
     return m.group(1) if m else None
 
 
@@ -46,9 +46,14 @@ def main():
         if "persistent" in r["kernel"] and r["kernel"].rstrip(">").endswith(", 1"):
             out["ff1_gemm_hbm_bytes_per_launch"] = r["hbm_bytes_per_launch"]
             break
+    # the bench's roofline kernel: pipelined self-attention (the launch with the largest grid = the DiT's self-attention)
+    att = [r for r in rows if "attn_pipe_kernel" in r["kernel"]]
+    if att:
+        out["attention_hbm_bytes_per_launch"] = max(att, key=lambda r: r["launches"])["hbm_bytes_per_launch"]
+    out["source"] = sys.argv[5] if len(sys.argv) > 5 else sys.argv[4]
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     with open(sys.argv[4], "w") as f:
-        f.write("# HBM traffic per launch from PMC counters (round 1)\n\n"
+        f.write("# HBM traffic per launch from PMC counters\n\n"
                 "`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes over "
                 "`python bench.py --steps 1 --warmup 1 --no-extras`; FETCH_SIZE x2 (gfx950 counts 64 B per "
                 "128-B request), both KiB -> bytes.\n\n| kernel | grid | launches | fetch MB | write MB | total MB |\n|---|---|---|---|---|---|\n")

@@ -8,7 +8,7 @@ import sys
 
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
-    m = re.match(r"(?:void )?(ltxmi::\w+(?:<[^>]*>)?)", name)
+    m = re.match(r"(?:void )?(ltxmi::(?:\w+::)*\w+(?:<[^>]*>)?)", name)
     if m:
         return m.group(1)
     m = re.match(r"(?:void )?(at::native::\w+)", name)
