@@ -198,22 +198,18 @@ def time_attention(device, n_tok, iters, B=1, heads=H, dh=DH, lk=None):
             "note": "QK^T and PV run at the same rate: fraction = (4 Lq Lk H dh / t) / peak = (2 Lq Lk H dh / (t/2)) / peak"}
 
 
-def time_vae(device, iters, grid=GRID, z_tile=0):
-    """CausalVideoAutoencoder.decode of z [1,128,*grid] with the 0.9.5+-style timestep-conditioned decoder
-    (create_video_autoencoder_demo_config(128), causal_video_autoencoder.py:1302-1338), timestep 0.05.
-    z_tile > 0: the reference's z-tiling (vae.py:365-402, tiles of z_tile + 1 latent frames, blends).
-    The untiled result is cross-checked against the same decode with every convolution as an implicit GEMM
-    (a second, independently tested implementation) before anything is timed."""
+def make_vae(device, grid=GRID, z_tile=0):
+    """The bench's decoder (0.9.5+-style timestep-conditioned, create_video_autoencoder_demo_config(128),
+    causal_video_autoencoder.py:1302-1338, random-init bf16), a latent z [1,128,*grid] and timestep 0.05."""
     import ltxmi
-    from ltxmi import ops
-    cfg = {"_class_name": "CausalVideoAutoencoder", "dims": 3, "in_channels": 3, "out_channels": 3, "latent_channels": 128,
-           "encoder_blocks": [], "blocks": [["res_x", {"num_layers": 4}], ["compress_all", {"residual": True}],
-                                            ["res_x", {"num_layers": 4}], ["compress_all", {"residual": True}],
-                                            ["res_x", {"num_layers": 4}], ["compress_all", {"residual": True}],
-                                            ["res_x", {"num_layers": 4}]],
-           "scaling_factor": 1.0, "norm_layer": "pixel_norm", "patch_size": 4, "latent_log_var": "uniform",
-           "use_quant_conv": False, "causal_decoder": False, "timestep_conditioning": True,
-           "spatial_padding_mode": "replicate", "decoder_base_channels": 128, "build_encoder": False}
+    blocks = [("res_x", {"num_layers": 2, "inject_noise": False}), ("compress_all", {"residual": True, "multiplier": 2}),
+              ("res_x", {"num_layers": 2, "inject_noise": False}), ("compress_all", {"residual": True, "multiplier": 2}),
+              ("res_x", {"num_layers": 2, "inject_noise": False}), ("compress_all", {"residual": True, "multiplier": 2}),
+              ("res_x", {"num_layers": 2, "inject_noise": False})]
+    cfg = {"_class_name": "CausalVideoAutoencoder", "dims": 3, "decoder_blocks": blocks, "latent_channels": C_LAT,
+           "norm_layer": "pixel_norm", "patch_size": 4, "latent_log_var": "uniform", "use_quant_conv": False,
+           "causal_decoder": False, "timestep_conditioning": True, "spatial_padding_mode": "replicate"}
+    # (decoder_base_channels defaults to 128: 1024 -> 512 -> 256 -> 128 feature channels, conv_out 128 -> 48)
     torch.manual_seed(5)
     with torch.device(device):
         vae = ltxmi.CausalVideoAutoencoder.from_config(dict(cfg))
@@ -223,6 +219,17 @@ def time_vae(device, iters, grid=GRID, z_tile=0):
     ts = torch.tensor([0.05], device=device)
     if z_tile:
         vae.enable_z_tiling(z_tile)
+    return vae, z, ts
+
+
+def time_vae(device, iters, grid=GRID, z_tile=0):
+    """CausalVideoAutoencoder.decode of z [1,128,*grid] with the decoder of make_vae.
+    z_tile > 0: the reference's z-tiling (vae.py:365-402, tiles of z_tile + 1 latent frames, blends).
+    The untiled result is cross-checked against the same decode with every convolution as an implicit GEMM
+    (a second, independently tested implementation) before anything is timed."""
+    import ltxmi
+    from ltxmi import ops
+    vae, z, ts = make_vae(device, grid, z_tile)
     check = {}
     with torch.no_grad():
         img = ltxmi.vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Side profiles of the round: the N = 98304 attention stress launch (MFMA busy, PMC) and a VAE decode (kernel stats).
+#   gpurun --timeout 900 -- 'bash tools/profile_extras.sh r02'
+set -eo pipefail
+TAG=${1:-rXX}
+OUT=$PWD/gpurun_out/prof
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+ROOT=$PWD
+cd /tmp
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+    --output-format csv -d "$OUT/attn" -o attn -- python3 "$ROOT/tools/attn_once.py" 98304 > "$OUT/attn.log" 2>&1
+python3 "$ROOT/tools/pmc_mfma.py" "$(find "$OUT/attn" -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_mfma_attn98304.md"
+echo "attention pmc done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/vae" -o vae -- python3 "$ROOT/tools/vae_time.py" 5 > "$OUT/vae.log" 2>&1
+python3 "$ROOT/tools/summarize_rocprof.py" "$(find "$OUT/vae" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_vae_kernel_stats.md" \
+    "rocprofv3 --kernel-trace --stats -- python tools/vae_time.py 5 (VAE decode 768x512x97, $TAG)"
+echo "vae stats done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
+    --output-format csv -d "$OUT/vaepmc" -o vaepmc -- python3 "$ROOT/tools/vae_time.py" 2 > "$OUT/vaepmc.log" 2>&1
+python3 "$ROOT/tools/pmc_mfma.py" "$(find "$OUT/vaepmc" -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_vae.md"
+rm -rf "$OUT/attn" "$OUT/vae" "$OUT/vaepmc"
+ls -la "$OUT"
