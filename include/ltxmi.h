@@ -157,6 +157,9 @@ int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* args, void* stream);
 /* 1 if ltxmi_attention_fwd_bf16 can normalise + rotate q on load for this shape, else 0 (the caller then runs
  * ltxmi_rmsnorm_rope_bf16 on q as a pass of its own).  Since 0.2 every shape the entry point accepts qualifies. */
 int ltxmi_attention_fuses_qnorm(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias);
+/* Identifier (>= 0) of the kernel instance ltxmi_attention_fwd_bf16 runs for this shape, -1 if unsupported.  Shapes with
+ * the same id get the same arithmetic per (batch, head, query row) -- e.g. B and B - 1 batch rows of one model call. */
+int ltxmi_attention_kernel_id(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias);
 
 /* Ulysses send buffer in one pass (sequence-parallel self-attention, xdit_context_parallel.py:149-184 of the reference
  * for Wan; here for the LTX DiT): q/k RMSNorm(weight) + interleaved RoPE exactly as ltxmi_rmsnorm_rope_bf16 and v,

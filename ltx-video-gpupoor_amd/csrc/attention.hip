@@ -519,6 +519,19 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     return a->key_bias ? launch<128, true, 1>(p, s) : launch<128, false, 1>(p, s);
 }
 
+// Which kernel instance ltxmi_attention_fwd_bf16 runs for a shape (mirrors the dispatch above).  Two shapes with the
+// same id are computed with the same arithmetic per (batch, head, query row): what ltxmi.Transformer3DModel checks before
+// it runs a sub-batch of rows and claims bit-identity with the full batch.
+extern "C" int ltxmi_attention_kernel_id(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias) {
+    if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
+    if (head_dim == 128) return has_key_bias ? 5 : 4;
+    if (head_dim != 64) return -1;
+    if (attn_pipe_takes(B, H, Lq, Lk, head_dim, has_key_bias != 0)) return 3;
+    const int64_t wg256 = (int64_t)B * H * ((Lq + 255) / 256);
+    if (wg256 >= 512 && !has_key_bias) return 2;
+    return has_key_bias ? 1 : 0;
+}
+
 extern "C" int ltxmi_attention_fuses_qnorm(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias) {
     // every kernel behind ltxmi_attention_fwd_bf16 normalises q on load (round 2: also the key-bias / small-shape /
     // head_dim-128 kernel); kept as a query so that callers written against it keep working

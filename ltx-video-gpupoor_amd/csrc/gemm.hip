@@ -309,8 +309,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
             v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
             v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
             if (EPI == LTXMI_EPI_GELU_TANH) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                // the packed form of the persistent kernel: every GEMM kernel produces the same bits for a given row
+                // (the accumulation order over K is the same in all of them), whatever M made the dispatcher choose
+                gelu_tanh_pk(v[0], v[1]);
+                gelu_tanh_pk(v[2], v[3]);
             } else if (EPI == LTXMI_EPI_SILU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);

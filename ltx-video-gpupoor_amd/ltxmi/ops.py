@@ -161,6 +161,11 @@ def attention_fuses_qnorm(B, H, Lq, Lk, dh, has_key_bias=False):
     return bool(lib.ltxmi_attention_fuses_qnorm(B, H, Lq, Lk, dh, int(has_key_bias)))
 
 
+def attention_kernel_id(B, H, Lq, Lk, dh, has_key_bias=False):
+    """Which kernel instance ``attention`` runs for a shape: equal ids = the same arithmetic per (batch, head, row)."""
+    return int(lib.ltxmi_attention_kernel_id(B, H, Lq, Lk, dh, int(has_key_bias)))
+
+
 def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None, rope=None, out_segments=None):
     """q [B,Lq,H,dh], k/v [B,Lk,H,dh] (NHD; batch and token strides free, (H,dh) contiguous).
     key_bias: fp32 [B,Lk] additive (broadcast over heads and queries).

@@ -200,8 +200,10 @@ class Transformer3DModel(nn.Module):
         """``stg_alias_blocks`` (extension, default off): the caller guarantees that the LAST batch row has
         exactly the inputs of the row before it (the STG "perturbed" row is the text row until its first
         skipped block, pipeline_ltx_video.py:1035-1051) -- the first ``stg_alias_blocks`` blocks then run on
-        B - 1 rows and the last row is filled in by a copy.  Bit-identical to running all rows (every kernel
-        computes a row independently of the others, in the same order)."""
+        B - 1 rows and the last row is filled in by a copy.  Bit-identical to running all rows: every kernel
+        computes a row independently of the others, the GEMM kernels all accumulate over K in the same order and share
+        their epilogue arithmetic (so the tile choice made from M does not matter), and the request is ignored when
+        B - 1 and B rows would be served by different self-attention kernels (``ops.attention_kernel_id``)."""
         if self.dtype != BF16:
             raise TypeError("ltxmi.Transformer3DModel runs in bfloat16 only: call .to(torch.bfloat16)")
         if mixed:
@@ -264,6 +266,10 @@ class Transformer3DModel(nn.Module):
             return m
 
         first_block = 0
+        if joint_pass and stg_alias_blocks and B >= 2:
+            heads, dh = self.num_attention_heads, self.attention_head_dim
+            if ops.attention_kernel_id(B, heads, N, N, dh) != ops.attention_kernel_id(B - 1, heads, N, N, dh):
+                stg_alias_blocks = 0                                        # a sub-batch would not reproduce the full batch's bits
         if joint_pass and stg_alias_blocks and B >= 2:
             first_block = min(int(stg_alias_blocks), len(self.transformer_blocks))
             keep = slice(0, B - 1)

@@ -94,6 +94,10 @@ def attention_fuses_qnorm(B, H, Lq, Lk, dh, has_key_bias=False):
     return False            # the double keeps q's normalisation as a pass of its own (both forms are kernel-tested on the GPU)
 
 
+def attention_kernel_id(B, H, Lq, Lk, dh, has_key_bias=False):
+    return 0
+
+
 def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None, rope=None, out_segments=None):
     assert q_norm is None and rope is None
     B, Lq, H, dh = q.shape
@@ -156,7 +160,7 @@ def stg_blend_(a, v, m_f32):
     return a
 
 
-NAMES = ["gemm", "norm_modulate", "rmsnorm_rope_", "attention_fuses_qnorm", "attention", "qkv_norm_rope_pack", "silu",
+NAMES = ["gemm", "norm_modulate", "rmsnorm_rope_", "attention_fuses_qnorm", "attention_kernel_id", "attention", "qkv_norm_rope_pack", "silu",
          "timestep_embedding", "stg_blend_"]
 
 

@@ -107,6 +107,13 @@ int main() {
         ++g_bad;
     }
 
+    if (ltxmi_attention_kernel_id(3, 32, 4992, 4992, 64, 0) != 3 || ltxmi_attention_kernel_id(1, 4, 100, 100, 64, 0) != 0 ||
+        ltxmi_attention_kernel_id(3, 32, 4992, 256, 64, 1) != 1 || ltxmi_attention_kernel_id(1, 12, 32760, 32760, 128, 0) != 4 ||
+        ltxmi_attention_kernel_id(1, 12, 100, 100, 96, 0) != -1) {
+        fprintf(stderr, "ltxmi_attention_kernel_id\n");
+        ++g_bad;
+    }
+
     // ---- row ops
     expect_fail(ltxmi_norm_modulate_bf16(nullptr, 0, nullptr, 0, 0, 0, 1e-6f, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr), "norm_modulate(NULL)");
     expect_fail(ltxmi_norm_modulate_bf16(p, 2048, p, 2048, 4992, 2048, 1e-6f, LTXMI_NORM_RMS, p, p, p, p, 2048 * 6, 4992, nullptr), "norm_modulate(no device)");

@@ -560,6 +560,25 @@ def test_adain_filter(dtype):
 
 
 # ------------------------------------------------------------------ randomised shape sweeps
+def test_gemm_kernels_agree_bit_for_bit():
+    """The dispatcher picks a kernel from M (128x128 tiles / 256x256 tiles / persistent).  All of them accumulate over K in
+    the same order with the same MFMA shape and share the epilogue arithmetic, so a row's result does not depend on the
+    choice -- which is what makes running a sub-batch of rows bit-identical to running them all (stg_alias_blocks)."""
+    from ltxmi import ops
+    for case, (M, N, K) in enumerate([(2048, 2048, 2048), (1500, 6144, 1024), (4992, 8192, 2048), (3000, 2048, 4096)]):
+        a, w, b = rnd(M, K, seed=40 + case).to(DEV), rnd(N, K, seed=50 + case, scale=K ** -0.5).to(DEV), rnd(N, seed=60 + case).to(DEV)
+        res = rnd(M, N, seed=70 + case).to(DEV)
+        gt, ge = rnd(N, seed=80 + case).to(DEV), rnd(3, N, seed=90 + case).to(DEV)
+        for epi in (ops.EPI_NONE, ops.EPI_GELU_TANH, ops.EPI_SILU, ops.EPI_GATE_RESIDUAL):
+            kw = dict(residual=res, gate_table=gt, gate_temb=ge, rows_per_group=(M + 2) // 3) if epi == ops.EPI_GATE_RESIDUAL else {}
+            outs = [ops.gemm(a, w, b, epilogue=epi, algo=al, **kw) for al in (0, 128, 256)]
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"gemm {M}x{N}x{K} epi {epi}: kernels differ"
+        # the same rows inside a taller problem (another tile choice, another tile position)
+        tall = torch.cat([a, a[: M // 2]], 0)
+        o_tall = ops.gemm(tall, w, b, epilogue=ops.EPI_GELU_TANH)
+        assert torch.equal(o_tall[:M], ops.gemm(a, w, b, epilogue=ops.EPI_GELU_TANH))
+
+
 def test_gemm_random_shapes_persistent_path():
     """Seeded random (M, N, K) on the persistent 256x256 kernel (M >= 1024, >= 384 tiles): ragged last
     M/N tiles through the per-tile buffer descriptors, odd tile counts per workgroup, every epilogue, a

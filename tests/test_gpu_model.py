@@ -166,6 +166,28 @@ def test_transformer_stg_row_alias_is_bit_identical():
         assert not torch.equal(full[1], full[2])            # the perturbation does act after block 2
 
 
+@pytest.mark.parametrize("grid,note", [((4, 24, 32), "B and B-1 rows on the same (pipelined) attention kernel, GEMM tile choice changes with M"),
+                                       ((4, 43, 64), "B rows on the pipelined attention kernel, B-1 rows not: aliasing is dropped")])
+def test_transformer_stg_row_alias_across_kernel_thresholds(grid, note):
+    """The same exactness where the dispatchers sit near their thresholds: 4 heads x 64, N = 3072 (the GEMM tile
+    choice and tile positions of a row change with M; attention kernel ids equal) and
+    N = 11008 (3 x 4 x 43 = 516 workgroups >= 512 for B = 3, 344 for B = 2: different attention kernels)."""
+    from ltxmi import SkipLayerStrategy, ops
+    cfg, sd32, x, enc, mask, ts, frac = dit_case(4, 64, 2, grid, 3, 16, seed=13)
+    x[2], enc[2], mask[2], ts[2] = x[1], enc[1], mask[1], ts[1]
+    m = build_model(cfg, sd32)
+    N = grid[0] * grid[1] * grid[2]
+    same = ops.attention_kernel_id(3, 4, N, N, 64) == ops.attention_kernel_id(2, 4, N, N, 64)
+    assert same == (N == 3072), note
+    fc = m.precompute_freqs_cis(frac.to(DEV))
+    slm = m.create_skip_layer_mask(1, 3, 2, [1])
+    kw = dict(freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV), timestep=ts.to(DEV),
+              skip_layer_mask=slm, skip_layer_strategy=SkipLayerStrategy.AttentionValues, latent_shape=grid, return_dict=False)
+    full = m(x.to(DEV).clone(), **kw)[0]
+    dedup = m(x.to(DEV).clone(), stg_alias_blocks=1, **kw)[0]
+    assert torch.equal(full, dedup), note
+
+
 def test_transformer_interrupt_and_output_types():
     import ltxmi
     grid, B, T = (2, 2, 4), 1, 16
