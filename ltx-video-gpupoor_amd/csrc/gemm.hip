@@ -58,12 +58,12 @@ struct GemmParams {
     // buffer of the Ulysses return all-to-all, [P source ranks][rows][D / P], is consumed in place by to_out
     int a_kblk; int64_t a_kblk_stride;
 
-    __device__ __forceinline__ int64_t a_koff(int kt) const {       // element offset of k-tile kt inside a row of A
-        const int kk = kt * 64;
+    __device__ __forceinline__ int64_t a_koff_elems(int kk) const { // element offset of column kk inside a row of A
         if (a_kblk <= 0) return kk;
         const int blk = kk / a_kblk;
         return (int64_t)blk * a_kblk_stride + (kk - blk * a_kblk);
     }
+    __device__ __forceinline__ int64_t a_koff(int kt) const { return a_koff_elems(kt * 64); }   // ... of k-tile kt
 };
 
 constexpr int EPI_D2S = 4;   // internal: conv + pixel-shuffle(2,2,2) scatter (+ residual)
@@ -383,6 +383,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
 //     is the compile-time constant MI*NI: the first barrier after an epilogue waits with
 //     s_waitcnt vmcnt(MI*NI), i.e. for the older LDS-DMA only, not for the stores;
 // =====================================================================================
+// Diagnostic build only (-DLTXMI_GEMM_STAMPS, tools/gemm_stamps.py): s_memtime stamps around the sections of a K-tile,
+// summed per wave into a debug buffer.  No stamp executes in the product build.
+#ifdef LTXMI_GEMM_STAMPS
+#define GSTAMP(i)                                                                              \
+    do {                                                                                       \
+        unsigned long long t_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        gst_acc[i] += t_ - gst_prev;                                                           \
+        gst_prev = t_;                                                                         \
+    } while (0)
+__device__ unsigned long long* g_gemm_stamps = nullptr;
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+
 #ifndef LTXMI_GEMM_DMA_WAVES
 #define LTXMI_GEMM_DMA_WAVES 4      // waves of the workgroup that issue the LDS-DMA: the older wave of each SIMD pair
                                     // wins MFMA-issue arbitration and otherwise idles ~900 cycles at the barrier (8 = all: -0.7 %)
@@ -396,8 +413,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int A_INSTR = (BM / 8) / NW;
     constexpr int B_INSTR = (BN / 8) / NW;
-    constexpr int N_STORES = (MI / 2) * 4 + (EPI == EPI_SUMSQ ? MI : 0);   // buffer stores per wave and tile
-    static_assert(MI % 2 == 0 && WN == 64, "epilogue scratch is a 32 x 64 bf16 chunk per wave");
+    constexpr int NH = WN / 64;             // 64-column halves of a wave's sub-tile (epilogue works on 32 x 64 chunks)
+    constexpr int NE = 4;                   // fragments (16 columns each) per half
+    constexpr int N_STORES = NH * ((MI / 2) * 4 + (EPI == EPI_SUMSQ ? MI : 0));   // buffer stores per wave and tile
+    static_assert(MI % 2 == 0 && WN % 64 == 0, "epilogue scratch is a 32 x 64 bf16 chunk per wave");
     static_assert(N_STORES <= 63, "vmcnt immediate is 6 bits");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -419,7 +438,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     const int my_n = lw < xcnt ? (xcnt - lw + nw_x - 1) / nw_x : 0;
     if (my_n == 0) return;
     constexpr int GN = 8;
-    auto tile_origin = [&](int i, int& m0, int& n0) {
+    auto tile_origin = [&](int i, int& m0, int& n0) __attribute__((always_inline)) {
         const int tile = x0 + lw + i * nw_x;
         const int band_sz = p.tiles_m * GN;
         const int band = tile / band_sz, rem = tile % band_sz;
@@ -436,7 +455,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     // Piece q of an operand is rows 8q .. 8q+7 of the tile: its per-lane offset is the offset of piece 0
     // (row srow, 16-byte slot sslot ^ srow) plus q * 8 rows -- one VGPR per operand instead of one per piece.
     // DMA_WAVES waves issue the pieces (PPW per operand each).
-    constexpr int DMA_WAVES = LTXMI_GEMM_DMA_WAVES;
+    constexpr int DMA_WAVES = LTXMI_GEMM_DMA_WAVES < NW ? LTXMI_GEMM_DMA_WAVES : NW;
     constexpr int PPW_A = (BM / 8) / DMA_WAVES, PPW_B = (BN / 8) / DMA_WAVES;     // pieces per DMA wave
     const uint32_t aoff0 = (uint32_t)(srow * (int)p.lda * 2 + ((sslot ^ srow) << 4));
     const uint32_t boff0 = (uint32_t)(srow * (int)p.ldw * 2 + ((sslot ^ srow) << 4));
@@ -446,32 +465,34 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     using rsrc_t = __amdgpu_buffer_rsrc_t;
     // (the resource type can be neither a struct member, nor bound to a reference, nor captured by a
     // lambda in the host pass: descriptors are plain locals passed BY VALUE)
-    auto rsrc_a = [&](int m0) {
+    auto rsrc_a = [&](int m0) __attribute__((always_inline)) {
         // (K-blocked A: the descriptor spans all blocks; rows past M then read other rows' data instead of zeros --
         // their results are never stored)
         const int64_t span = p.a_kblk > 0 ? (int64_t)(p.K / p.a_kblk - 1) * p.a_kblk_stride + p.a_kblk : p.K;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0,
                                                  (int)(((int64_t)(min(BM, p.M - m0) - 1) * p.lda + span) * 2), 0x00020000);
     };
-    auto rsrc_w = [&](int n0) {
+    auto rsrc_w = [&](int n0) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw), 0,
                                                  (int)(((int64_t)(min(BN, p.N - n0) - 1) * p.ldw + p.K) * 2), 0x00020000);
     };
     // one 1-KB piece (8 rows x 128 B) of k-tile kt: this wave's pieces 0..PPW_A-1 are A, the rest W
-    auto piece = [&](int buf, rsrc_t ta, rsrc_t tw, int kt, int g) {
+    // (akb: byte offset of k-tile kt inside a row of A, computed once per k-tile -- a division when A is K-blocked)
+    auto piece = [&](int buf, rsrc_t ta, rsrc_t tw, int kt, int akb, int g) __attribute__((always_inline)) {
         char* sa = smem + buf * STAGE_BYTES;
         if (g < PPW_A) {
             const int q = wave * PPW_A + g;
-            blds16(ta, sa + q * 1024, aoff0 + (uint32_t)(q * a_step), (int)(p.a_koff(kt) * 2));
+            blds16(ta, sa + q * 1024, aoff0 + (uint32_t)(q * a_step), akb);
         } else {
             const int q = wave * PPW_B + (g - PPW_A);
             blds16(tw, sa + A_BYTES + q * 1024, boff0 + (uint32_t)(q * b_step), kt * (BK * 2));
         }
     };
-    auto stage = [&](int buf, rsrc_t ta, rsrc_t tw, int kt) {
+    auto stage = [&](int buf, rsrc_t ta, rsrc_t tw, int kt) __attribute__((always_inline)) {
         if (dma_wave) {
+            const int akb = (int)(p.a_koff(kt) * 2);
 #pragma unroll
-            for (int g = 0; g < PPW_A + PPW_B; ++g) piece(buf, ta, tw, kt, g);
+            for (int g = 0; g < PPW_A + PPW_B; ++g) piece(buf, ta, tw, kt, akb, g);
         }
     };
 
@@ -502,12 +523,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     // through LDS every store instruction writes 8 whole 128-byte lines, 16 bytes per lane, and the
     // instruction count halves (the store tail is issue-bound: cdna guide T21).
     char* scr = smem + 2 * STAGE_BYTES + wave * 4096;
-    auto epilogue = [&](int m0, int n0) {
-        u32x2 bias_v[NI], gt_v[NI];
-        int ncl[NI];
+    auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn * WN + j * 16 + ecol;
+      for (int jh = 0; jh < NH; ++jh) {                                   // one 64-column half of the sub-tile at a time
+        const int nh0 = n0 + wn * WN + jh * 64;
+        u32x2 bias_v[NE], gt_v[NE];
+        int ncl[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int n = nh0 + j * 16 + ecol;
             ncl[j] = n < p.N ? n : p.N - 4;
             bias_v[j] = *(const u32x2*)(p.bias + ncl[j] * p.bias_stride);
             if (GATED) gt_v[j] = *(const u32x2*)(p.gate_table + ncl[j]);
@@ -520,17 +544,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
                 const int m = m0 + wm * WM + i * 16 + erow;
                 const int mc = m < p.M ? m : p.M - 1;                 // clamped row for the reads
                 const uint16_t* gate_row = GATED ? p.gate_temb + (int64_t)(mc / p.rows_per_group) * p.gate_ld : nullptr;
-                u32x2 ge_v[NI], rr_v[NI];
+                u32x2 ge_v[NE], rr_v[NE];
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
+                for (int j = 0; j < NE; ++j) {
                     if (GATED) ge_v[j] = *(const u32x2*)(gate_row + ncl[j]);
                     if (RESID) rr_v[j] = *(const u32x2*)(p.R + (int64_t)mc * p.ldr + ncl[j]);
                 }
                 const int row_l = ii * 16 + erow;
                 float ss = 0.f;
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                for (int j = 0; j < NE; ++j) {
+                    const f32x4 a4 = acc[i][jh * NE + j];
+                    float v[4] = {a4[0], a4[1], a4[2], a4[3]};
                     v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
                     v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
                     if (EPI == LTXMI_EPI_GELU_TANH) {
@@ -560,12 +585,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
                     *(u32x2*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4) + ((lane >> 4) & 1) * 8) = o;
                 }
                 if (EPI == EPI_SUMSQ) {
-                    // this wave's 64 columns of row m: lanes l, l+16, l+32, l+48 hold its four 16-column pieces
+                    // these 64 columns of row m: lanes l, l+16, l+32, l+48 hold its four 16-column pieces
                     ss += __shfl_xor(ss, 16, 64);
                     ss += __shfl_xor(ss, 32, 64);
-                    const int nb = n0 + wn * WN;
-                    const uint32_t off = (lane < 16 && m < p.M && nb < p.sumsq_cols)
-                                             ? (uint32_t)(((int64_t)m * p.sumsq_ld + (nb >> 6)) * 4) : 0xfffffff0u;
+                    const uint32_t off = (lane < 16 && m < p.M && nh0 < p.sumsq_cols)
+                                             ? (uint32_t)(((int64_t)m * p.sumsq_ld + (nh0 >> 6)) * 4) : 0xfffffff0u;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ss), ss_rsrc, off, 0, 0);
                 }
             }
@@ -575,13 +599,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
                 const int row_l = t * 8 + (lane >> 3), chunk = lane & 7;
                 const u32x4 w = *(const u32x4*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4));
                 const int m = m0 + wm * WM + c * 32 + row_l;
-                const int n = n0 + wn * WN + chunk * 8;
+                const int n = nh0 + chunk * 8;
                 const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((int64_t)m * p.ldc + n) * 2) : 0xfffffff0u;
                 __builtin_amdgcn_raw_buffer_store_b128(w, c_rsrc, off, 0, 0);
             }
         }
+      }
     };
 
+#ifdef LTXMI_GEMM_STAMPS
+    unsigned long long gst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gst_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gst_prev)::"memory");
+#endif
     const int nk = p.K / BK;                 // >= 2 on this path
     int cs_m0, cs_n0, ns_m0 = 0, ns_n0 = 0;
     tile_origin(0, cs_m0, cs_n0);
@@ -599,7 +628,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     constexpr int MI_HEAD = MI > 2 ? 2 : 1;
     // phase A of one K-tile: MFMAs on the k-step-0 fragments, k-step-1 fragment reads in between.
     // FIRST: first K-tile of an output tile, accumulate onto 0 (fresh accumulator values per tile).
-    auto phase_a = [&](const char* s, auto first_tag) {
+    constexpr int PPW = PPW_A + PPW_B;                          // LDS-DMA pieces of a DMA wave per K-tile
+    auto phase_a = [&](const char* s, auto first_tag) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
         for (int i = 0; i < MI_HEAD; ++i)
@@ -620,13 +650,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
                     bf0[j], af0[i], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto read_f0 = [&](const char* sn) {
+    auto read_f0 = [&](const char* sn) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) af0[i] = *(const bf16x8*)(sn + a_off0 + i * 2048);
 #pragma unroll
         for (int j = 0; j < NI; ++j) bf0[j] = *(const bf16x8*)(sn + b_off0 + j * 2048);
     };
-    auto mfma_f1 = [&]() {
+    auto mfma_f1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -635,7 +665,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
         __builtin_amdgcn_sched_barrier(0);
     };
     // barrier between the phases: the LDS-DMA of the NEXT k-tile must have landed
-    auto sync_all = [&]() {
+    auto sync_all = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
@@ -647,16 +677,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     // no MFMA.  One piece goes out per MFMA row, so a wave waiting on its piece is covered by its SIMD
     // partner's MFMAs.  READ_F0: also fetch the next k-step-0 fragments (not on a tile's last K-tile:
     // they would have to live through the epilogue).
-    constexpr int PPR = (PPW_A + PPW_B + MI - 1) / MI;          // pieces per MFMA row (DMA waves only)
-    auto phase_b_rows = [&](int cur, rsrc_t ta, rsrc_t tw, int kts, bool do_stage, auto f0_tag) {
+    // (akb = byte offset of k-tile kts inside a row of A: the caller computes it, and chooses the descriptors, BEFORE
+    // phase A -- with one wave per SIMD every scalar instruction between the barrier and the first MFMA of phase B is
+    // matrix-pipe idle time)
+    auto phase_b_rows = [&](int cur, rsrc_t ta, rsrc_t tw, int kts, int akb, bool do_stage, auto f0_tag) __attribute__((always_inline)) {
         constexpr bool READ_F0 = decltype(f0_tag)::value;
+        constexpr int NP = PPW;
         const char* sn = smem + (cur ^ 1) * STAGE_BYTES;
 #pragma unroll
         for (int g = 0; g < MI; ++g) {
             if (do_stage && dma_wave) {
+                // row g's share: pieces [g NP / MI, (g + 1) NP / MI)
 #pragma unroll
-                for (int q = 0; q < PPR; ++q)
-                    if (g * PPR + q < PPW_A + PPW_B) piece(cur, ta, tw, kts, g * PPR + q);
+                for (int q = (g * NP) / MI; q < ((g + 1) * NP) / MI; ++q) piece(cur, ta, tw, kts, akb, q);
             }
             if (READ_F0) {
                 // A rows first (two per MFMA row), then the W fragments
@@ -675,14 +708,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // phase B of a K-tile that is not the tile's last: refill the drained stage with k-tile (+2) of the
-    // (tile, k-tile) stream -- this tile's, or the next tile's first (its descriptors are scalars) --
-    // fetch the next k-step-0 fragments, MFMAs on k-step 1.  ONE copy of the MFMA rows.
-    auto phase_b_mid = [&](int cur, int kt, bool has_next, rsrc_t ca, rsrc_t cw, rsrc_t na, rsrc_t nw) {
-        const bool same_tile = kt + 2 < nk;
-        phase_b_rows(cur, same_tile ? ca : na, same_tile ? cw : nw, same_tile ? kt + 2 : kt + 2 - nk,
-                     same_tile || has_next, std::integral_constant<bool, true>{});
-    };
     using first_t = std::integral_constant<bool, true>;
     using next_t = std::integral_constant<bool, false>;
 
@@ -694,9 +719,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             ns_a = rsrc_a(ns_m0);
             ns_w = rsrc_w(ns_n0);
         }
+        // What phase B of K-tile kt stages: k-tile (+2) of the (tile, k-tile) stream -- this tile's, or one of the next
+        // tile's first two (its descriptors are scalars).  Chosen before phase A (see phase_b_rows).
+#define LTXMI_GEMM_PICK_STAGE(KT)                                                         \
+        const bool same_tile = (KT) + 2 < nk;                                              \
+        const int kts = same_tile ? (KT) + 2 : (KT) + 2 - nk;                              \
+        const rsrc_t st_a = same_tile ? cs_a : ns_a, st_w = same_tile ? cs_w : ns_w;      \
+        const int akb = (int)(p.a_koff(kts) * 2);                                          \
+        const bool do_stage = same_tile || has_next;                                       \
+        __builtin_amdgcn_sched_barrier(0);
         // ---- K-tile 0 (never the last: nk >= 2)
         {
             const int cur = flat & 1;
+            LTXMI_GEMM_PICK_STAGE(0)
             phase_a(smem + cur * STAGE_BYTES, first_t{});
             // right after an epilogue the N_STORES younger buffer stores may still be in flight:
             // wait for everything older than them (the LDS-DMA) only
@@ -707,26 +742,46 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             } else {
                 sync_all();
             }
-            phase_b_mid(cur, 0, has_next, cs_a, cs_w, ns_a, ns_w);
+            phase_b_rows(cur, st_a, st_w, kts, akb, do_stage, std::integral_constant<bool, true>{});
             ++flat;
         }
         // ---- middle K-tiles
         for (int kt = 1; kt < nk - 1; ++kt) {
             const int cur = flat & 1;
+            LTXMI_GEMM_PICK_STAGE(kt)
+            GSTAMP(4);                                                   // (scalar set-up + loop overhead + first/last K-tiles)
             phase_a(smem + cur * STAGE_BYTES, next_t{});
+            GSTAMP(0);
+#ifdef LTXMI_GEMM_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GSTAMP(1);
+#endif
             sync_all();
-            phase_b_mid(cur, kt, has_next, cs_a, cs_w, ns_a, ns_w);
+            GSTAMP(2);
+            phase_b_rows(cur, st_a, st_w, kts, akb, do_stage, std::integral_constant<bool, true>{});
+            GSTAMP(3);
+#ifdef LTXMI_GEMM_STAMPS
+            gst_acc[5] += 1;
+#endif
             ++flat;
         }
+#undef LTXMI_GEMM_PICK_STAGE
         // ---- last K-tile, then the epilogue under the next tile's loads
         {
             const int cur = flat & 1;
+            const int akb1 = (int)(p.a_koff(1) * 2);
+            __builtin_amdgcn_sched_barrier(0);
             phase_a(smem + cur * STAGE_BYTES, next_t{});
             sync_all();
             // next tile's K-tile 1 goes into the stage this K-tile just drained, piece by piece under the
             // MFMAs; all of it is issued BEFORE the stores, so vmcnt(N_STORES) at the next barrier covers it
-            phase_b_rows(cur, ns_a, ns_w, 1, has_next, std::integral_constant<bool, false>{});
+            phase_b_rows(cur, ns_a, ns_w, 1, akb1, has_next, std::integral_constant<bool, false>{});
+            GSTAMP(4);
             epilogue(cs_m0, cs_n0);
+            GSTAMP(6);
+#ifdef LTXMI_GEMM_STAMPS
+            gst_acc[7] += 1;
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (has_next) {
                 cs_a = ns_a; cs_w = ns_w; cs_m0 = ns_m0; cs_n0 = ns_n0;
@@ -737,6 +792,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             ++flat;
         }
     }
+#ifdef LTXMI_GEMM_STAMPS
+    if (g_gemm_stamps && lane == 0 && blockIdx.x < 256) {
+        // [0] phase A, [1] vmcnt wait, [2] barrier, [3] phase B (middle K-tiles); [4] everything else in the K loops;
+        // [5] middle K-tiles counted; [6] epilogues; [7] tiles
+        unsigned long long* o = g_gemm_stamps + (blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = gst_acc[i];
+    }
+#endif
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
@@ -792,7 +855,10 @@ static int launch_persistent(const GemmParams& p0, int epi, hipStream_t stream, 
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, stream, p);                        \
     }
     switch (epi) {
-        case LTXMI_EPI_NONE: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_NONE) break;
+        // the plain epilogue runs on the row-sums instance with the sums switched off (sumsq_cols = 0: its extra stores
+        // carry an out-of-range offset and are dropped): same bits, and measured 3-6 % faster than a dedicated instance,
+        // which hipcc happens to allocate worst of all (55 spilled VGPRs)
+        case LTXMI_EPI_NONE:
         case EPI_SUMSQ: LTXMI_GEMM_LAUNCH_P(EPI_SUMSQ) break;
         case LTXMI_EPI_GELU_TANH: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_GELU_TANH) break;
         case LTXMI_EPI_SILU: LTXMI_GEMM_LAUNCH_P(LTXMI_EPI_SILU) break;
@@ -892,6 +958,13 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     }
     return launch_tile<128, 128, 2, 2, 0>(p, epi, s, "ltxmi_gemm_bf16");
 }
+
+#ifdef LTXMI_GEMM_STAMPS
+extern "C" int ltxmi_debug_set_gemm_stamps(void* buf) {
+    unsigned long long* b = (unsigned long long*)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(ltxmi::g_gemm_stamps), &b, sizeof(b));
+}
+#endif
 
 extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream) {
     LTXMI_REQUIRE(a && a->x && a->w && a->y, LTXMI_ERR_INVALID_ARG, "ltxmi_conv3d_ndhwc_bf16: NULL argument");

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""A/B two builds of libltxmi.so on the hot GEMM shapes inside ONE process (alternating launches on the
-same tensors, so clocks / box / data are common to both arms).
-    python tools/ab_gemm.py path/to/libA.so path/to/libB.so
-"""
+"""A/B several builds of libltxmi.so on the hot GEMM shapes inside ONE process (alternating launches on the same tensors,
+so clocks / box / data are common to all arms); the first library is the reference of the ratios and of a bit-equality check.
+    python tools/ab_gemm.py path/to/libA.so path/to/libB.so [libC.so ...]"""
 import ctypes
 import os
 import sys
@@ -22,23 +21,37 @@ def load(path):
 
 
 def main():
-    libs = [load(p) for p in sys.argv[1:3]]
-    shapes = [(14976, 8192, 2048, 1), (14976, 2048, 8192, 0), (14976, 6144, 2048, 0), (14976, 2048, 2048, 0),
-              (8192, 8192, 8192, 0)]
+    libs = [load(p) for p in sys.argv[1:]]
+    names = [os.path.basename(p) for p in sys.argv[1:]]
+    shapes = [(14976, 8192, 2048, 1, "ff1"), (14976, 2048, 8192, 3, "ff2"), (14976, 6144, 2048, 0, "qkv"),
+              (14976, 6144, 2048, 6, "qkv+ss"), (14976, 2048, 2048, 6, "q2+ss"),
+              (14976, 2048, 2048, 3, "to_out"), (4992, 8192, 2048, 1, "ff1 B1"), (8192, 8192, 8192, 0, "8k^3")]
     stream = torch.cuda.current_stream().cuda_stream
-    for (M, N, K, epi) in shapes:
+    for (M, N, K, epi, name) in shapes:
         a = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
         w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
         b = torch.randn(N, device="cuda").to(torch.bfloat16)
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        res = torch.randn(M, N, device="cuda").to(torch.bfloat16)
         g = _lib.GemmArgs()
         g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc = a.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), out.data_ptr(), N
-        g.M, g.N, g.K, g.epilogue = M, N, K, epi
-        times = [[], []]
-        for rep in range(6):
+        g.M, g.N, g.K, g.epilogue = M, N, K, (0 if epi == 6 else epi)
+        if epi == 6:                                 # plain epilogue + row sums of squares over the first 2048 columns
+            ss = torch.empty(M, 32, device="cuda", dtype=torch.float32)
+            g.rowsumsq, g.rowsumsq_cols, g.rowsumsq_ld = ss.data_ptr(), 2048, 32
+        if epi == 3:
+            g.residual, g.ldr = res.data_ptr(), N
+        times = [[] for _ in libs]
+        ref = None
+        for rep in range(7):
             for i, lib in enumerate(libs):
                 for _ in range(3):
-                    lib.ltxmi_gemm_bf16(ctypes.byref(g), stream)
+                    assert lib.ltxmi_gemm_bf16(ctypes.byref(g), stream) == 0
+                if rep == 0:
+                    if ref is None:
+                        ref = out.clone()
+                    elif not torch.equal(ref, out):
+                        print(f"  !! {names[i]} differs from {names[0]}: max {float((ref.float() - out.float()).abs().max()):.4g}")
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(10):
@@ -48,8 +61,7 @@ def main():
                 if rep > 0:
                     times[i].append(e0.elapsed_time(e1) / 10)
         med = [sorted(t)[len(t) // 2] for t in times]
-        tf = [2.0 * M * N * K / m / 1e9 for m in med]
-        print(f"{M}x{N}x{K} epi{epi}:  A {med[0]:.4f} ms {tf[0]:7.1f} TF   B {med[1]:.4f} ms {tf[1]:7.1f} TF   B/A {tf[1] / tf[0]:.3f}",
+        print(f"{name:7s} {M}x{N}x{K} epi{epi}: " + " | ".join(f"{n} {m:.4f} ms {2.0 * M * N * K / m / 1e9:7.1f} TF x{med[0] / m:.3f}" for n, m in zip(names, med)),
               flush=True)
 
 

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostic only: read the in-kernel s_memtime stamps of a stamped build of the persistent GEMM
-(GEMM notes) after running the FF1 shape.  Usage: LTXMI_LIB=.../libltxmi_stamp.so python tools/gemm_stamps.py"""
+"""Diagnostic only: in-kernel s_memtime stamps of a stamped build of the persistent GEMM (-DLTXMI_GEMM_STAMPS, see
+gemm.hip) on the hot shapes, for the product kernel (algo 0: 8 waves of 128x64) and the one-wave-per-SIMD variant
+(algo 4: 4 waves of 128x128).
+    make -C ltx-video-gpupoor_amd/csrc stamps && LTXMI_LIB=ltx-video-gpupoor_amd/ltxmi/libltxmi_stamp.so python tools/gemm_stamps.py"""
 import ctypes
 import os
 import sys
@@ -8,26 +10,40 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "ltx-video-gpupoor_amd")):
     sys.path.insert(0, p)
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from ltxmi import ops, _lib  # noqa: E402
 
-for (M, N, K, epi) in [(14976, 8192, 2048, ops.EPI_GELU_TANH), (8192, 8192, 8192, ops.EPI_NONE)]:
-    a = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
-    w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
-    b = torch.randn(N, device="cuda").to(torch.bfloat16)
-    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    for _ in range(30):
-        ops.gemm(a, w, b, out=out, epilogue=epi)
-    torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * (256 * 8 * 8))()
-    _lib.lib.ltxmi_debug_read_stamps.restype = ctypes.c_int
-    rc = _lib.lib.ltxmi_debug_read_stamps(buf)
-    d = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8, 8).astype(np.float64)
-    n = d[..., 5]
-    print(f"shape {M}x{N}x{K}: rc {rc}; per middle K-tile, cycles (median over waves; wave 0 / wave 7 of the median workgroup)")
-    for name, idx in (("slot 0 (see the stamped build)", 0), ("vmcnt wait", 1), ("barrier", 2), ("slot 3 (see the stamped build)", 3)):
-        v = d[..., idx] / np.maximum(n, 1)
-        print(f"  {name:42s} {np.median(v):8.0f}   w0 {np.median(v[:, 0]):8.0f}  w7 {np.median(v[:, 7]):8.0f}")
-    tiles = d[..., 7]
-    print(f"  epilogue per tile {np.median(d[..., 4] / np.maximum(tiles, 1)):8.0f};  whole kernel per wave {np.median(d[..., 6]):10.0f} cycles, tiles per WG {np.median(tiles):.1f}")
+dev = torch.device("cuda", 0)
+buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
+_lib.lib.ltxmi_debug_set_gemm_stamps.restype = ctypes.c_int
+_lib.lib.ltxmi_debug_set_gemm_stamps.argtypes = [ctypes.c_void_p]
+assert _lib.lib.ltxmi_debug_set_gemm_stamps(buf.data_ptr()) == 0
+algos = [int(a) for a in sys.argv[1:]] or [0, 4]
+for (M, N, K, epi, name) in [(14976, 8192, 2048, ops.EPI_GELU_TANH, "ff1"), (14976, 2048, 8192, ops.EPI_GATE_RESIDUAL, "ff2"),
+                             (8192, 8192, 8192, ops.EPI_NONE, "8k^3")]:
+    a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=dev).to(torch.bfloat16)
+    out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    res = torch.randn(M, N, device=dev).to(torch.bfloat16) if epi == ops.EPI_GATE_RESIDUAL else None
+    for al in algos:
+        for _ in range(20):
+            ops.gemm(a, w, b, out=out, epilogue=epi, residual=res, algo=al)
+        buf.zero_()
+        ops.gemm(a, w, b, out=out, epilogue=epi, residual=res, algo=al)
+        torch.cuda.synchronize()
+        nw = 4 if al == 4 else 8
+        d = buf.cpu().numpy().reshape(256, 8, 8)[:, :nw].astype("float64")
+        n = d[..., 5].clip(min=1)
+        tiles = d[..., 7].clip(min=1)
+        import numpy as np
+        med = lambda x: float(np.median(x))
+        pa, vm, bar, pb = (med(d[..., i] / n) for i in range(4))
+        unit, bound = ("mini-tile (K 32)", 1024) if al == 4 else ("middle K-tile", 2048)
+        extra = f"  other {med(d[..., 4] / n):5.0f}" if al == 4 else ""
+        print(f"{name} {M}x{N}x{K} algo {al}: per {unit} (median over waves): MFMA phase A {pa:6.0f}  vmcnt {vm:5.0f}  barrier {bar:5.0f}  "
+              f"phase B {pb:6.0f}{extra}  = {pa + vm + bar + pb + (med(d[..., 4] / n) if al == 4 else 0):6.0f} cycles (pipe-bound: {bound});  "
+              f"epilogue/tile {med(d[..., 6] / tiles):7.0f};  rest/tile {med(d[..., 4] / tiles):7.0f};  tiles/WG {med(tiles):.1f}", flush=True)
+        w0, wl = d[:, 0], d[:, nw - 1]
+        print(f"      wave 0: A {med(w0[:, 0] / n[:, 0]):6.0f} barrier {med(w0[:, 2] / n[:, 0]):5.0f} B {med(w0[:, 3] / n[:, 0]):6.0f}   "
+              f"wave {nw - 1}: A {med(wl[:, 0] / n[:, nw - 1]):6.0f} barrier {med(wl[:, 2] / n[:, nw - 1]):5.0f} B {med(wl[:, 3] / n[:, nw - 1]):6.0f}")
