@@ -352,7 +352,19 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL prints a five-line version banner on STDOUT when the first communicator is created; rank 0's stdout
+        # must carry the one JSON line only, so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=device)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from ltxmi import ops
     ops.set_step_invariant_caching(False)     # headline: every timed step does all the work of the reference's step

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of the GEMM kernels selectable through ltxmi_gemm_args.algo on the hot shapes (alternating launches on
-the same tensors): 0 = the product's choice (persistent, 8 waves of 128x64), 4 = persistent with 4 waves of 128x128.
+the same tensors): 0 = the product's choice (persistent 256x256), 256 = the non-persistent 256x256 kernel, 128 = 128x128
+tiles (round 2 also had 4 / 5 = experimental K loops here, see profiles/r02_gemm_ring_w4.log).
     python tools/ab_gemm_algo.py [algo ...]"""
 import os
 import sys
@@ -13,7 +14,7 @@ from ltxmi import ops  # noqa: E402
 
 
 def main():
-    algos = [int(a) for a in sys.argv[1:]] or [0, 4]
+    algos = [int(a) for a in sys.argv[1:]] or [0, 256]
     dev = torch.device("cuda", 0)
     shapes = [(14976, 8192, 2048, ops.EPI_GELU_TANH, "ff1"), (14976, 2048, 8192, ops.EPI_GATE_RESIDUAL, "ff2"),
               (14976, 6144, 2048, ops.EPI_NONE, "qkv"), (14976, 2048, 2048, ops.EPI_GATE_RESIDUAL, "to_out"),
