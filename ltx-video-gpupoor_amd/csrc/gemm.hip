@@ -77,6 +77,17 @@ __device__ __attribute__((aligned(16))) uint32_t g_zero_page[16];
 
 constexpr int BK = 64;
 
+// s + the squares of four stored bf16 values, as ONE fixed chain of fused multiply-adds: under -ffast-math hipcc is free to
+// associate "s += a*a + b*b + c*c + d*d" differently in every kernel instance, and the row sums of squares (which become
+// q's RMSNorm factor) must not depend on which GEMM kernel the dispatcher picked for a given M
+__device__ __forceinline__ float sumsq4(float s, u32x2 o) {
+    s = __builtin_fmaf(bf_lo(o[0]), bf_lo(o[0]), s);
+    s = __builtin_fmaf(bf_hi(o[0]), bf_hi(o[0]), s);
+    s = __builtin_fmaf(bf_lo(o[1]), bf_lo(o[1]), s);
+    s = __builtin_fmaf(bf_hi(o[1]), bf_hi(o[1]), s);
+    return s;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int MODE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(GemmParams p) {
     constexpr int NW = WAVES_M * WAVES_N;
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_kernel(Gem
             o[1] = pack_bf16(v[2], v[3]);
             *(u32x2*)(p.C + (int64_t)m * p.ldc + n) = o;
             if (EPI == EPI_SUMSQ)
-                ss[j / 4] += bf_lo(o[0]) * bf_lo(o[0]) + bf_hi(o[0]) * bf_hi(o[0]) + bf_lo(o[1]) * bf_lo(o[1]) + bf_hi(o[1]) * bf_hi(o[1]);
+                ss[j / 4] = sumsq4(ss[j / 4], o);
         }
         if (EPI == EPI_SUMSQ) {
             static_assert(EPI != EPI_SUMSQ || NI % 4 == 0, "sum-of-squares partials are per 64 columns");
@@ -579,7 +590,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
                     o[0] = pack_bf16(v[0], v[1]);
                     o[1] = pack_bf16(v[2], v[3]);
                     if (EPI == EPI_SUMSQ)
-                        ss += bf_lo(o[0]) * bf_lo(o[0]) + bf_hi(o[0]) * bf_hi(o[0]) + bf_lo(o[1]) * bf_lo(o[1]) + bf_hi(o[1]) * bf_hi(o[1]);
+                        ss = sumsq4(ss, o);
                     // 8-byte piece (j*4 + lane>>4) of scratch row row_l; 16-byte chunks XOR-swizzled by row
                     const int chunk = j * 2 + (lane >> 5);
                     *(u32x2*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4) + ((lane >> 4) & 1) * 8) = o;

@@ -573,6 +573,13 @@ def test_gemm_kernels_agree_bit_for_bit():
             kw = dict(residual=res, gate_table=gt, gate_temb=ge, rows_per_group=(M + 2) // 3) if epi == ops.EPI_GATE_RESIDUAL else {}
             outs = [ops.gemm(a, w, b, epilogue=epi, algo=al, **kw) for al in (0, 128, 256)]
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"gemm {M}x{N}x{K} epi {epi}: kernels differ"
+        # the row sums of squares the QKV projection hands to the attention kernel (q's RMSNorm factor)
+        sums = []
+        for al in (0, 128, 256):
+            ss = torch.zeros(M, N // 64, device=DEV)
+            o = ops.gemm(a, w, b, algo=al, rowsumsq=ss, rowsumsq_cols=N)
+            sums.append(ss)
+        assert torch.equal(sums[0], sums[1]) and torch.equal(sums[0], sums[2]), f"gemm {M}x{N}x{K}: row sums of squares differ between kernels"
         # the same rows inside a taller problem (another tile choice, another tile position)
         tall = torch.cat([a, a[: M // 2]], 0)
         o_tall = ops.gemm(tall, w, b, epilogue=ops.EPI_GELU_TANH)

@@ -244,6 +244,38 @@ def test_transformer_2b_one_block_full_size():
     assert_parity(out, truth, eager, "2B-width, 1 block, N 4992, B_eff 3")
 
 
+def test_transformer_2b_full_depth():
+    """The whole 2B model: all 28 layers at the real widths (D 2048, 32 x 64 heads, FF 8192, caption 4096, T 256), B_eff 3
+    with the STG row perturbed from block 19 (the 2B default), on an eighth-size token grid (N = 624) so that the two CPU
+    oracle runs (fp32 truth, bf16 eager) finish in about a minute.  Error accumulated through the full depth must stay
+    within the rounding the reference's own bf16 eager run accumulates."""
+    import ltxmi
+    from oracle import dit
+    grid, B, T = (2, 13, 24), 3, 256
+    cfg, sd32, x, enc, mask, ts, frac = dit_case(32, 64, 28, grid, B, T, caption=4096, seed=26)
+    skip = dit.create_skip_layer_mask(28, 1, 3, 2, [19], torch.float32)
+    truth, eager = run_oracles(cfg, sd32, x, enc, mask, ts, frac, grid, skip_layer_mask=skip,
+                               skip_layer_strategy=dit.ATTENTION_VALUES)
+    m = build_model(cfg, sd32)
+    del sd32
+    fc = m.precompute_freqs_cis(frac.to(DEV))
+    kw = dict(freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV), timestep=ts.to(DEV),
+              skip_layer_mask=m.create_skip_layer_mask(1, 3, 2, [19]), skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues,
+              latent_shape=grid, ltxv_model=_Holder(), return_dict=False)
+    out = m(x.to(DEV), **kw)[0]
+    assert out.shape == (3, 624, 128)
+    assert_parity(out, truth, eager, "2B, 28 layers, N 624, B_eff 3")
+    # and the pipeline's row de-duplication over the 19 blocks before the first skipped one: same bits
+    x2 = x.clone()
+    x2[2] = x2[1]
+    enc2, mask2, ts2 = enc.clone(), mask.clone(), ts.clone()
+    enc2[2], mask2[2], ts2[2] = enc2[1], mask2[1], ts2[1]
+    kw.update(encoder_hidden_states=enc2.to(DEV), encoder_attention_mask=mask2.to(DEV), timestep=ts2.to(DEV))
+    full = m(x2.to(DEV).clone(), **kw)[0]
+    dedup = m(x2.to(DEV).clone(), stg_alias_blocks=19, **kw)[0]
+    assert torch.equal(full, dedup)
+
+
 # ------------------------------------------------------------------------------- VAE
 def vae_case(style, base=64, latent=128, seed=0, with_encoder=False):
     from oracle import vae as ov
