@@ -5,7 +5,7 @@
 // the narrow layers of the VAE decoder: DESIGN.md section 5).
 //
 //   output tile  : 2 (t) x 8 (y) x 16 (x) = 256 positions x 128 output channels, 8 waves (4 position groups x
-//                  2 channel halves, 64 x 64 per wave, 4 x 4 MFMA 16x16x32 blocks)
+//                  2 channel halves, 64 x 64 per wave, 4 x 4 MFMA 16x16x32 blocks; a half beyond Cout is not computed)
 //   LDS          : halo 4 x 10 x 18 = 720 rows x 128 B (64 channels) = 90 KB, 16-byte slots XOR-swizzled by
 //                  row & 7 (on the DMA source side); weights 2 stages x 128 rows x 128 B = 32 KB
 //   per chunk    : halo DMA (90 pieces), then per tap: next tap's weight DMA (2 pieces per wave) || fragment
@@ -46,7 +46,9 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     char* wst = smem + CD_HALO_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    // waves 0..3 (one per SIMD) take the first 64 output channels of the block, waves 4..7 the second 64: when the block's
+    // second half lies beyond Cout (conv_out: 48 channels) the waves that still work are spread over all four SIMDs
+    const int wm = wave & 3, wn = wave >> 2;
 
     // ---- tile: blockIdx.x -> (n block fastest, then x, y, t, b): the n blocks of a position tile are neighbours
     int id = blockIdx.x;
@@ -137,10 +139,14 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
         __syncthreads();
     };
     // one tap: weights of tap + 2 start streaming, fragments of tap + 1 are read, MFMAs of tap
+    // a wave whose 64 output channels all lie beyond Cout only helps with the loads and barriers
+    const bool active = n0 + wn * 64 < p.Cout;
     auto tap_body = [&](int tap, int c0, auto cur_tag, auto nxt_tag) {
         if (tap + 2 < 27) load_w((tap + 2) % CD_WSTAGES, tap + 2, c0);
-        if (tap + 1 < 27) read_frags(nxt_tag, tap + 1);
-        mfmas(cur_tag);
+        if (active) {
+            if (tap + 1 < 27) read_frags(nxt_tag, tap + 1);
+            mfmas(cur_tag);
+        }
         sync_all();
     };
 
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
         load_w(0, 0, c0);
         load_w(1, 1, c0);
         sync_all();
-        read_frags(s0_t{}, 0);
+        if (active) read_frags(s0_t{}, 0);
         for (int tap = 0; tap < 26; tap += 2) {
             tap_body(tap, c0, s0_t{}, s1_t{});
             tap_body(tap + 1, c0, s1_t{}, s0_t{});
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
 
     // ---- epilogue: bias (+ add), bf16, through a 4 KB per-wave LDS scratch (the halo is free after the last
     // barrier) so that every store instruction writes whole 128-byte rows (16 bytes per lane)
+    if (!active) return;                                   // (the last barrier of the tap loop is behind every wave)
     char* scr = smem + wave * 4096;
     const int ecol = (lane >> 4) * 4;
     u32x2 bias_v[4];
