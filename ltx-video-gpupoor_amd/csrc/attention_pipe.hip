@@ -284,7 +284,16 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
             // rounding to bf16 at the end.
             const float* ss = p.q_ss + (int64_t)b * p.q_ss_sb + (int64_t)q_ld * p.q_ss_sl;
             float s2 = 0.f;
-            for (int j = 0; j < p.q_ss_n; ++j) s2 += ss[j];
+            if ((p.q_ss_n & 3) == 0 && (((uintptr_t)ss) & 15) == 0) {
+                // (one 16-byte load per four partials: the row's partials are contiguous)
+                const f32x4* ss4 = (const f32x4*)ss;
+                for (int j = 0; j < (p.q_ss_n >> 2); ++j) {
+                    const f32x4 v4 = ss4[j];
+                    s2 += (v4[0] + v4[1]) + (v4[2] + v4[3]);
+                }
+            } else {
+                for (int j = 0; j < p.q_ss_n; ++j) s2 += ss[j];
+            }
             const float rstd = rsqrtf(s2 / (float)(p.H * DH) + p.q_eps);
             const int64_t trow = (int64_t)b * p.rope_sb + (int64_t)q_ld * p.rope_sl;
 #pragma unroll

@@ -28,6 +28,9 @@ from .attention_seam import pay_attention
 BF16 = torch.bfloat16
 
 
+FUSE_CROSS_ATTENTION_Q = False     # see AttnProcessor2_0 (cross-attention branch)
+
+
 class SkipLayerStrategy(Enum):          # ltx_video/utils/skip_layer_strategy.py:4-8
     AttentionSkip = auto()
     AttentionValues = auto()
@@ -259,9 +262,11 @@ class AttnProcessor2_0:
             v3 = qkv.view(B, N, 3 * D)[:, :, 2 * D:]
         else:
             Bk, Lk, _ = encoder_hidden_states.shape
-            # q's RMSNorm is applied by the attention kernel while it loads q (as in self-attention): the projection
-            # emits the per-row sums of squares, q gets no pass of its own
-            fuse_q = D % 64 == 0 and bool(ops.attention_fuses_qnorm(B, H, N, Lk, dh, attention_mask is not None))
+            # q's RMSNorm could be applied by the attention kernel while it loads q, as in self-attention (the kernel
+            # supports it and is tested).  With 256 text keys it does not pay: every head's workgroups re-derive the
+            # row factor and the kernel's short life is mostly prologue -- measured 83.2 us fused against 20.9 + 60.9 us
+            # (tools/xattn_time.py) -- so q keeps a pass of its own here.
+            fuse_q = FUSE_CROSS_ATTENTION_Q and D % 64 == 0 and bool(ops.attention_fuses_qnorm(B, H, N, Lk, dh, attention_mask is not None))
             ss = torch.empty((B * N, D // 64), dtype=torch.float32, device=x2.device) if fuse_q else None
             q2 = ops.gemm(x2, attn.to_q.weight, attn.to_q.bias, rowsumsq=ss, rowsumsq_cols=D if fuse_q else 0)   # [B*N, D]
             # The text keys/values depend on the prompt and this layer's weights only: within a generation
