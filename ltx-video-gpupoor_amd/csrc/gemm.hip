@@ -881,14 +881,21 @@ static int launch_persistent(const GemmParams& p0, int epi, hipStream_t stream, 
     return check_launch(what);
 }
 
-// device address of the zero page (stands in for a missing bias with stride 0)
+// device address of the zero page of the CURRENT device (stands in for a missing bias with stride 0); a __device__
+// symbol has one address per device, so the cache is per device like the other launcher state (common.h)
 static const uint16_t* zero_page_ptr() {
-    static const uint16_t* ptr = nullptr;
-    if (!ptr) {
-        void* d = nullptr;
-        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_page)) == hipSuccess) ptr = (const uint16_t*)d;
+    static const uint16_t* ptrs[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked) {
+        const uint16_t* c = __atomic_load_n(&ptrs[dev], __ATOMIC_ACQUIRE);
+        if (c) return c;
     }
-    return ptr;
+    void* d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_page)) != hipSuccess) return nullptr;
+    if (tracked) __atomic_store_n(&ptrs[dev], (const uint16_t*)d, __ATOMIC_RELEASE);
+    return (const uint16_t*)d;
 }
 
 }  // namespace ltxmi
