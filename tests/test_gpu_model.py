@@ -900,3 +900,98 @@ def test_ulysses_processor_world1_matches_default_processor():
         if created:
             dist.destroy_process_group()
     assert torch.equal(out, ref)
+
+
+# ------------------------------------------------------------------------------- Ulysses at world size 2, real kernels
+def _host_staged_collectives():
+    """gloo moves CPU tensors only: for device tensors the three collectives of ltxmi.distributed are staged through
+    the host IN THE TEST WORKERS (the product code is untouched; on a multi-GPU node the same calls go to RCCL)."""
+    import torch.distributed as dist
+    a2a, gather, reduce = dist.all_to_all_single, dist.all_gather, dist.all_reduce
+
+    def all_to_all_single(recv, send, group=None, **kw):
+        if not send.is_cuda:
+            return a2a(recv, send, group=group, **kw)
+        r, s = torch.empty(recv.shape, dtype=recv.dtype), send.cpu()
+        a2a(r, s, group=group, **kw)
+        recv.copy_(r)
+
+    def all_gather(parts, x, group=None, **kw):
+        if not x.is_cuda:
+            return gather(parts, x, group=group, **kw)
+        host = [torch.empty(p.shape, dtype=p.dtype) for p in parts]
+        gather(host, x.cpu(), group=group, **kw)
+        for p, h in zip(parts, host):
+            p.copy_(h)
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, group=None, **kw):
+        if not t.is_cuda:
+            return reduce(t, op=op, group=group, **kw)
+        h = t.cpu()
+        reduce(h, op=op, group=group, **kw)
+        t.copy_(h)
+
+    dist.all_to_all_single, dist.all_gather, dist.all_reduce = all_to_all_single, all_gather, all_reduce
+
+
+def _ulysses_world2_worker(rank, world, port, per_token, q):
+    import os
+    import sys
+    import traceback
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "ltx-video-gpupoor_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)                                  # both ranks share the one GPU of the box
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        _host_staged_collectives()
+        import ltxmi
+        from ltxmi import distributed as sp
+        grid, B, T = (4, 16, 16), 3, 32                           # N = 1024 tokens, 512 per rank, 2 frames per rank
+        cfg, sd32, x, enc, mask, ts, frac = dit_case(4, 64, 2, grid, B, T, seed=31, per_token=per_token)
+        m = build_model(cfg, sd32)
+        fc = m.precompute_freqs_cis(frac.to(DEV))
+        kw = dict(encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV), timestep=ts.to(DEV),
+                  skip_layer_mask=m.create_skip_layer_mask(1, 3, 2, [1]),
+                  skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=grid)
+        with torch.no_grad():
+            ref = m(x.to(DEV).clone(), freqs_cis=fc, return_dict=False, **kw)[0]      # one rank, default processor
+            sp.enable_sequence_parallel(m)
+            out = sp.usp_dit_forward(m, x.to(DEV).clone(), fc, **kw)[0]               # tokens sharded over 2 ranks
+        torch.cuda.synchronize()
+        err = float((out.float() - ref.float()).norm() / ref.float().norm())
+        assert out.shape == ref.shape and torch.isfinite(out.float()).all()
+        # same kernels on the same rows; only the GEMM tile positions and the heads-per-launch of attention differ
+        assert err < 2e-3, err
+        q.put((rank, "ok", err))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        q.put((rank, traceback.format_exc(), None))
+
+
+@pytest.mark.parametrize("per_token", [False, True])
+def test_ulysses_world2_real_kernels_on_one_gpu(per_token):
+    """usp_dit_forward + UlyssesAttnProcessor at WORLD SIZE 2 with the real kernels: two processes share the box's one
+    GPU, the all-to-alls travel over gloo (host-staged in the workers).  Everything device-side is what runs on a
+    multi-GPU node -- the destination-major pack kernel with P = 2, the token-major strided attention input, the
+    segmented attention output, the K-blocked to_out GEMM, the sliced RoPE tables, per-token timesteps -- only the
+    transport differs.  Against the single-rank forward of the same model."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ulysses_world2_worker, args=(r, 2, port, per_token, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, err in results:
+        assert status == "ok", f"rank {rank}:\n{status}"
