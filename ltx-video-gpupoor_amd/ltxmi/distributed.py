@@ -95,7 +95,13 @@ class UlyssesAttnProcessor:
         all_to_all_single   recv  [P src][B*Nl][D/P]: the K-blocked A operand of to_out, consumed in place
         to_out GEMM (+ gate + residual epilogue)
 
-    No pack / unpack copy exists anywhere (the first version of this path spent 10 % of a step in them)."""
+    No pack / unpack copy exists anywhere (the first version of this path spent 10 % of a step in them).
+
+    Differences from AttnProcessor2_0, both deliberate: (1) the reference's shortcut for an all-perturbed batch under
+    the AttentionValues strategy (skip attention and return v, attention.py:1060-1062) is not taken -- attention always
+    runs and the STG blend then selects v for the perturbed rows: the same values, and every rank issues the same
+    collectives whatever its rows are; (2) an ``attention_mask`` for self-attention is not supported (the reference's
+    LTX path never passes one, transformer3d.py:411-415 builds the mask for the text keys only)."""
 
     def __init__(self, group=None):
         self.group = group
@@ -108,6 +114,8 @@ class UlyssesAttnProcessor:
         hidden_states = hidden_states_wrapper[0]
         hidden_states_wrapper.clear()
         assert encoder_hidden_states is None, "UlyssesAttnProcessor is for self-attention"
+        if attention_mask is not None:
+            raise NotImplementedError("UlyssesAttnProcessor: a self-attention mask is not on this path")
         P = dist.get_world_size(self.group)
         B, Nl, _ = hidden_states.shape
         D, H = attn.inner_dim, attn.heads
