@@ -484,6 +484,9 @@ def main():
                          "bound": "mfma", "achieved": round(at_tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(at_tf / MFMA_BF16_PEAK_TFLOPS, 4),
                          "traffic": traffic.get("attention_hbm_bytes_per_launch"), "traffic_source": tnote,
+                         # north star: "achieved HBM GB/s on attention" = PMC bytes per launch over this run's launch time
+                         "hbm_gb_per_s": (round(traffic["attention_hbm_bytes_per_launch"] / (r["at_ms"] * 1e-3) / 1e9, 1)
+                                          if traffic.get("attention_hbm_bytes_per_launch") and r["at_ms"] > 0 else None),
                          "launch_ms": round(r["at_ms"], 4), "launches_timed": r["n_at"],
                          "algorithmic_flop_per_launch": at_flop,
                          "algorithmic_bytes_per_launch": 8 * NUM_CONDS * N_TOK * (D // sp)},
