@@ -45,15 +45,16 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MIC
 D, H, DH, L, FF, T_TEXT, C_LAT = 2048, 32, 64, 28, 8192, 256, 128
 GRID = (13, 16, 24)                  # 768x512x97 -> latent frames/height/width
 N_TOK = GRID[0] * GRID[1] * GRID[2]  # 4992
+GRID_CONFIG3 = (16, 22, 38)          # 1216x704x121 -> 13376 tokens (BASELINE config 3, i2v)
 NUM_CONDS = 3
 
 
-def fractional_coords(device):
+def fractional_coords(device, grid=None):
     """What LTXVideoPipeline hands to precompute_freqs_cis (pipeline_ltx_video.py:1086-1088): seconds on the time
     axis (25 fps, causal fix), pixels on y / x.  Product-side helpers only: nothing under oracle/ is used outside
     the cpu_baseline leg."""
     from ltxmi.patchifier import SymmetricPatchifier, latent_to_pixel_coords_from_factors
-    coords = SymmetricPatchifier(1).get_latent_coords(*GRID, 1, device)
+    coords = SymmetricPatchifier(1).get_latent_coords(*(grid or GRID), 1, device)
     pc = latent_to_pixel_coords_from_factors(coords, (8, 32, 32), causal_fix=True).to(torch.float32)
     pc[:, 0] = pc[:, 0] * (1.0 / 25.0)
     return pc
@@ -100,9 +101,8 @@ class StepRunner:
         emb, mask, neg, nmask = synth_inputs(device)
         self.embeds = torch.cat([neg, emb, emb])
         self.mask = torch.cat([nmask, mask, mask])
-        g = torch.Generator(device=device).manual_seed(1)
-        self.latents = torch.randn(1, N_TOK, C_LAT, generator=g, device=device, dtype=torch.float32)
-        self.freqs = self.m.precompute_freqs_cis(fractional_coords(device))
+        self.device = device
+        self.set_grid(GRID)
         self.skip = self.m.create_skip_layer_mask(1, NUM_CONDS, NUM_CONDS - 1, [19])
         self.ws = torch.empty(ops.GUIDANCE_WORKSPACE_FLOATS, device=device)
         sch = RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1)       # OURS_SCHEDULER_CONFIG
@@ -112,10 +112,27 @@ class StepRunner:
         self.dt = float(ts[10] - ts[11])
         self.t_dev = torch.full((NUM_CONDS, 1), self.t, device=device)
         self.t_dev1 = torch.full((1, 1), self.t, device=device)
+        self.t_global = self.t_dev
 
         class Holder:
             _interrupt = False
         self.holder = Holder()
+
+    def set_grid(self, grid, image_conditioned=False):
+        """Latents, RoPE tables (and, image_conditioned: the per-token timesteps of an i2v step -- the first latent frame
+        is the conditioning image, pipeline_ltx_video.py:1157-1166) for a latent grid (frames, height, width)."""
+        device = self.device
+        self.grid = tuple(grid)
+        self.n_tok = grid[0] * grid[1] * grid[2]
+        g = torch.Generator(device=device).manual_seed(1)
+        self.latents = torch.randn(1, self.n_tok, C_LAT, generator=g, device=device, dtype=torch.float32)
+        self.freqs = self.m.precompute_freqs_cis(fractional_coords(device, self.grid))
+        if image_conditioned:
+            t = torch.full((NUM_CONDS, self.n_tok), self.t, device=device)
+            t[:, : grid[1] * grid[2]] = 0.0
+            self.t_dev = t
+        elif hasattr(self, "t_global"):
+            self.t_dev = self.t_global
 
     def enable_ulysses(self):
         """One video over all ranks: tokens sharded, all-to-all inside self-attention (ltxmi.distributed)."""
@@ -128,7 +145,7 @@ class StepRunner:
         """B_eff = 1: the text row only (no CFG, no STG; guidance scale 1 leaves the prediction as it is)."""
         x = self.latents.to(torch.bfloat16)
         noise_pred = self.m(x, freqs_cis=self.freqs, encoder_hidden_states=self.embeds[1:2],
-                            encoder_attention_mask=self.mask[1:2], timestep=self.t_dev1, latent_shape=GRID,
+                            encoder_attention_mask=self.mask[1:2], timestep=self.t_dev1, latent_shape=self.grid,
                             ltxv_model=self.holder, return_dict=False)[0]
         self.ops.guidance_step_(noise_pred, self.latents, self.dt, 1.0, 0.0, 1.0, False, False, False, self.ws)
 
@@ -139,14 +156,14 @@ class StepRunner:
             noise_pred = self.sp.usp_dit_forward(
                 self.m, x, self.freqs, encoder_hidden_states=self.embeds, encoder_attention_mask=self.mask,
                 timestep=self.t_dev, skip_layer_mask=self.skip,
-                skip_layer_strategy=self.ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=GRID,
+                skip_layer_strategy=self.ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=self.grid,
                 ltxv_model=self.holder)[0]
             self.ops.guidance_step_(noise_pred.contiguous(), self.latents, self.dt, 3.0, 1.0, 0.7, True, True, True,
                                     self.ws)
             return
         noise_pred = self.m(x, freqs_cis=self.freqs, encoder_hidden_states=self.embeds,
                             encoder_attention_mask=self.mask, timestep=self.t_dev, skip_layer_mask=self.skip,
-                            skip_layer_strategy=self.ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=GRID,
+                            skip_layer_strategy=self.ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=self.grid,
                             ltxv_model=self.holder, return_dict=False, stg_alias_blocks=stg_alias_blocks)[0]
         self.ops.guidance_step_(noise_pred, self.latents, self.dt, 3.0, 1.0, 0.7, True, True, True, self.ws)
 
@@ -414,9 +431,9 @@ def main():
 
     def measure(ulysses):
         sp = world if ulysses else 1                          # token (and, inside attention, head) shards
-        M = NUM_CONDS * N_TOK // sp
+        M = NUM_CONDS * runner.n_tok // sp
         key_ff1 = ("gemm", M, FF, D, ops.EPI_GELU_TANH)
-        key_attn = ("attention", NUM_CONDS, H // sp, N_TOK, N_TOK, DH)
+        key_attn = ("attention", NUM_CONDS, H // sp, runner.n_tok, runner.n_tok, DH)
         for _ in range(args.warmup):
             runner.step()
         ops.watch_launches([key_ff1, key_attn])
@@ -430,7 +447,7 @@ def main():
         return {"elapsed": elapsed, "per_step": per_step, "sp": sp, "M": M, "ff1_ms": ff1_ms, "n_ff1": len(ff1),
                 "at_ms": at_ms, "n_at": len(at)}
 
-    uly = None
+    uly = uly3 = None
     if ulysses_only:
         runner.enable_ulysses()
         r = measure(True)
@@ -444,6 +461,15 @@ def main():
                 uly = measure(True)
             except Exception as e:  # noqa: BLE001  (symmetric failures only: every rank runs the same code)
                 uly = {"error": f"{type(e).__name__}: {e}"[:400]}
+            # BASELINE config 3, the workload the Ulysses mode is named for: 2B i2v 1216x704x121 = 16 x 22 x 38 = 13376
+            # tokens, first latent frame conditioned (per-token timesteps), one video over the ranks
+            if "error" not in uly:
+                try:
+                    runner.set_grid(GRID_CONFIG3, image_conditioned=True)
+                    uly3 = measure(True)
+                except Exception as e:  # noqa: BLE001
+                    uly3 = {"error": f"{type(e).__name__}: {e}"[:400]}
+                runner.set_grid(GRID)
             runner.sp = None
     ms_per_step = r["elapsed"] / args.steps * 1e3
     value = (1 if ulysses_only else world) * args.steps / r["elapsed"]
@@ -497,6 +523,19 @@ def main():
                               "launch_ms": round(r["ff1_ms"], 4), "launches_timed": r["n_ff1"],
                               "algorithmic_flop_per_launch": ff1_flop},
         }
+        if uly3 is not None:
+            n3 = GRID_CONFIG3[0] * GRID_CONFIG3[1] * GRID_CONFIG3[2]
+            if "error" in uly3:
+                line["ulysses_config3"] = {"error": uly3["error"]}
+            else:
+                line["ulysses_config3"] = {
+                    "workload": "LTX-Video 2B i2v 1216x704x121 (13376 tokens, first latent frame conditioned: per-token timesteps), "
+                                "B_eff 3, one video over the ranks", "tokens": n3, "parallelism": f"ulysses sp{world}",
+                    "value": round(args.steps / uly3["elapsed"], 4), "unit": "denoise-steps/s (ONE video)", "scaling": "strong",
+                    "ms_per_step": round(uly3["elapsed"] / args.steps * 1e3, 2),
+                    "step_ms": {"median": round(pct(uly3["per_step"], 0.5), 3), "p10": round(pct(uly3["per_step"], 0.1), 3),
+                                "p90": round(pct(uly3["per_step"], 0.9), 3)},
+                    "attention_launch_ms": round(uly3["at_ms"], 4)}
         if uly is not None and "error" in uly:
             line["ulysses"] = {"error": uly["error"], "parallelism": f"ulysses sp{world}"}
         elif uly is not None:
