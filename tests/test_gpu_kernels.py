@@ -168,7 +168,7 @@ def test_attention_online_softmax_rescale_branch():
 @pytest.mark.parametrize("Lq,Lk,spike", [(256, 1, False), (256, 64, False), (300, 65, False), (257, 130, False),
                                          (256, 200, False), (512, 448, True), (256, 1029, True)])
 def test_attention_pipelined_kernel_edges(Lq, Lk, spike):
-    """Shapes with >= 512 query tiles of 256 rows take the software-pipelined LDS-DMA kernel
+    """Shapes with >= 192 query tiles of 256 rows take the software-pipelined LDS-DMA kernel
     (attention_pipe.hip).  Its edges: a single (ragged) key tile, exactly one full tile, one full + a ragged
     tile, key tiles whose ring slots are never filled, ragged query tiles, and the rescale branch with the
     running max jumping late (block A and block B of a wave at different tiles)."""

@@ -167,11 +167,12 @@ def test_transformer_stg_row_alias_is_bit_identical():
 
 
 @pytest.mark.parametrize("grid,note", [((4, 24, 32), "B and B-1 rows on the same (pipelined) attention kernel, GEMM tile choice changes with M"),
-                                       ((4, 43, 64), "B rows on the pipelined attention kernel, B-1 rows not: aliasing is dropped")])
+                                       ((4, 32, 32), "B rows on the pipelined attention kernel, B-1 rows not: aliasing is dropped")])
 def test_transformer_stg_row_alias_across_kernel_thresholds(grid, note):
     """The same exactness where the dispatchers sit near their thresholds: 4 heads x 64, N = 3072 (the GEMM tile
     choice and tile positions of a row change with M; attention kernel ids equal) and
-    N = 11008 (3 x 4 x 43 = 516 workgroups >= 512 for B = 3, 344 for B = 2: different attention kernels)."""
+    N = 4096 (3 x 4 x 16 = 192 workgroups of 256 rows >= the pipelined kernel's threshold for B = 3, 128 for B = 2:
+    different attention kernels)."""
     from ltxmi import SkipLayerStrategy, ops
     cfg, sd32, x, enc, mask, ts, frac = dit_case(4, 64, 2, grid, 3, 16, seed=13)
     x[2], enc[2], mask[2], ts[2] = x[1], enc[1], mask[1], ts[1]
