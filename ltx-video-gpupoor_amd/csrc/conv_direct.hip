@@ -29,6 +29,23 @@ struct ConvDirectP {
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page_cd[16];
 
+// Diagnostic build only (-DLTXMI_CONV_STAMPS, tools/conv_stamps.py): s_memtime stamps around the sections of a tap,
+// summed per wave into a debug buffer.  No stamp executes in the product build.
+#ifdef LTXMI_CONV_STAMPS
+#define CSTAMP(i)                                                                              \
+    do {                                                                                       \
+        unsigned long long t_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        cst_acc[i] += t_ - cst_prev;                                                           \
+        cst_prev = t_;                                                                         \
+    } while (0)
+__device__ unsigned long long* g_conv_stamps = nullptr;
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+
 constexpr int CD_TT = 2, CD_TY = 8, CD_TX = 16;
 constexpr int CD_HT = CD_TT + 2, CD_HY = CD_TY + 2, CD_HX = CD_TX + 2;
 constexpr int CD_HALO_ROWS = CD_HT * CD_HY * CD_HX;            // 720
@@ -59,22 +76,57 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     const int b = id / p.tiles_t;
     const int t0 = tt * CD_TT, y0 = ty * CD_TY, x0 = tx * CD_TX, n0 = nb * 128;
 
-    // ---- halo loader: piece q = rows 8q .. 8q+7; lane -> (row 8q + lane>>3, LDS slot lane&7, source slot ^ row&7)
+    // ---- halo loader: piece q = rows 8q .. 8q+7; lane -> (row 8q + lane>>3, LDS slot lane&7, source slot ^ row&7).
+    // Where a halo row comes from depends on the tile only, not on the 64-channel chunk: the per-lane byte offsets of
+    // this wave's 11-12 pieces are computed ONCE (stamps: the div/mod/clamp arithmetic per piece made the issue of a
+    // chunk's halo take 4500 cycles, with no MFMA running), and a chunk's loads are then one buffer_load ... lds per
+    // piece with the chunk's channel offset as the scalar offset.  Rows that are zero padding get an offset past the
+    // descriptor's range: the hardware delivers zeros.
+    constexpr int HP = (CD_HALO_ROWS / 8 + 7) / 8;                           // pieces per wave (90 pieces over 8 waves: 12)
+    const int64_t x_bytes = (int64_t)p.B * p.T * p.H * p.W * p.Cin * 2;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, 0, (int)(x_bytes < 0x7ffffff0ll ? x_bytes : 0x7ffffff0ll), 0x00020000);
     const int64_t xb = (int64_t)b * p.T * p.H * p.W * p.Cin;
-    auto load_halo = [&](int c0) {
-        for (int q = wave; q < CD_HALO_ROWS / 8; q += 8) {
-            const int r = q * 8 + (lane >> 3);
-            const int hx = r % CD_HX, hy = (r / CD_HX) % CD_HY, ht = r / (CD_HX * CD_HY);
-            int ti = t0 + ht - p.tpad, yi = y0 + hy - 1, xi = x0 + hx - 1;
-            const bool toob = (ti < 0) | (ti >= p.T);
-            const bool oob = (yi < 0) | (yi >= p.H) | (xi < 0) | (xi >= p.W);
-            ti = ti < 0 ? 0 : (ti >= p.T ? p.T - 1 : ti);
-            yi = yi < 0 ? 0 : (yi >= p.H ? p.H - 1 : yi);
-            xi = xi < 0 ? 0 : (xi >= p.W ? p.W - 1 : xi);
-            const uint16_t* src = p.x + xb + ((int64_t)(ti * p.H + yi) * p.W + xi) * p.Cin + c0 + (((lane & 7) ^ (r & 7)) << 3);
-            if ((oob && !p.pad_replicate) | (toob && p.tzero)) src = (const uint16_t*)g_zero_page_cd;
-            glds16(src, halo + q * 1024);
+    uint32_t hoff[HP];
+#pragma unroll
+    for (int k = 0; k < HP; ++k) {
+        const int q = wave + 8 * k;
+        const int r = q * 8 + (lane >> 3);
+        const int hx = r % CD_HX, hy = (r / CD_HX) % CD_HY, ht = r / (CD_HX * CD_HY);
+        int ti = t0 + ht - p.tpad, yi = y0 + hy - 1, xi = x0 + hx - 1;
+        const bool toob = (ti < 0) | (ti >= p.T);
+        const bool oob = (yi < 0) | (yi >= p.H) | (xi < 0) | (xi >= p.W);
+        ti = ti < 0 ? 0 : (ti >= p.T ? p.T - 1 : ti);
+        yi = yi < 0 ? 0 : (yi >= p.H ? p.H - 1 : yi);
+        xi = xi < 0 ? 0 : (xi >= p.W ? p.W - 1 : xi);
+        const int64_t e = xb + ((int64_t)(ti * p.H + yi) * p.W + xi) * p.Cin + (((lane & 7) ^ (r & 7)) << 3);
+        const bool zero = (oob && !p.pad_replicate) | (toob && p.tzero) | (q >= CD_HALO_ROWS / 8);
+        hoff[k] = zero ? 0x7ffffff0u : (uint32_t)(e * 2);
+    }
+    // pieces [q_lo, 90) of a chunk's halo
+    auto load_halo = [&](int c0, int q_lo) {
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const int q = wave + 8 * k;
+            if (q >= q_lo && q < CD_HALO_ROWS / 8) blds16(x_rsrc, halo + q * 1024, hoff[k], c0 * 2);
         }
+    };
+    // The halo is four t-planes of 180 rows, and the taps run dt-major: after tap 8 (dt = 0 done) plane 0 is dead, after
+    // tap 17 plane 1 is.  The NEXT chunk's rows for those planes are requested under the remaining taps -- pieces 0..21
+    // (rows 0..175) one per wave and tap at taps 9..11, pieces 22..44 (rows 176..359) at taps 18..21 -- so that only
+    // planes 2 and 3 (pieces 45..89) are loaded with the matrix pipe idle at the start of a chunk.
+    constexpr int Q_PLANE0 = 22, Q_PLANE1 = 45;
+    auto prefetch_halo = [&](int tap, int c_next) __attribute__((always_inline)) -> bool {
+        int k, lo, hi;
+        if (tap >= 9 && tap <= 11) { k = tap - 9; lo = 0; hi = Q_PLANE0; }
+        else if (tap >= 18 && tap <= 21) { k = tap - 16; lo = Q_PLANE0; hi = Q_PLANE1; }
+        else return false;
+        const int q = wave + 8 * k;
+        if (q < lo || q >= hi) return false;
+        // (a select, not hoff[k]: a runtime index would put the array into scratch memory)
+        const uint32_t off = k == 0 ? hoff[0] : k == 1 ? hoff[1] : k == 2 ? hoff[2] : k == 3 ? hoff[3] : k == 4 ? hoff[4] : hoff[5];
+        blds16(x_rsrc, halo + q * 1024, off, c_next * 2);
+        return true;
     };
     // ---- weights of one tap and chunk: rows n0 .. n0+127 of w [Cout, 27*Cin], 64 channels at (tap*Cin + c0)
     const int wrow0 = (wave * 2) * 8 + (lane >> 3);
@@ -134,39 +186,97 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     };
     using s0_t = std::integral_constant<int, 0>;
     using s1_t = std::integral_constant<int, 1>;
-    auto sync_all = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#ifdef LTXMI_CONV_STAMPS
+    unsigned long long cst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cst_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cst_prev)::"memory");
+#endif
+    // keep1: the youngest request of this wave is a prefetched halo piece of the NEXT chunk -- it may stay in flight
+    // across the barrier (the wait of the following tap covers it: requests complete in order)
+    auto sync_all = [&](bool keep1 = false) {
+        CSTAMP(0);                                               // [0] issue of loads + fragment reads + MFMAs of a tap
+        if (keep1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CSTAMP(1);                                               // [1] wait for this wave's LDS-DMA
+        // a bare s_barrier: __syncthreads() would first wait (lgkmcnt(0)) for the fragment reads of the next tap issued a
+        // moment ago -- ~290 cycles per tap with the matrix pipe idle (stamps).  Those reads target registers and read
+        // LDS regions that nothing overwrites before the NEXT barrier (the weight stage of tap + 1, halo planes still in
+        // use), so they may stay in flight across this one; hipcc waits for them where the MFMAs consume them.
+        asm volatile("s_barrier" ::: "memory");
+        CSTAMP(2);                                               // [2] barrier
     };
     // one tap: weights of tap + 2 start streaming, fragments of tap + 1 are read, MFMAs of tap
     // a wave whose 64 output channels all lie beyond Cout only helps with the loads and barriers
     const bool active = n0 + wn * 64 < p.Cout;
-    auto tap_body = [&](int tap, int c0, auto cur_tag, auto nxt_tag) {
+    auto tap_body = [&](int tap, int c0, int c_next, auto cur_tag, auto nxt_tag) __attribute__((always_inline)) {
+        CSTAMP(3);
         if (tap + 2 < 27) load_w((tap + 2) % CD_WSTAGES, tap + 2, c0);
+        const bool pf = c_next >= 0 && prefetch_halo(tap, c_next);     // AFTER the weight pieces: it is the youngest request
+        CSTAMP(6);                                               // [6] issue of the weight pieces (+ a prefetched halo piece)
         if (active) {
-            if (tap + 1 < 27) read_frags(nxt_tag, tap + 1);
-            mfmas(cur_tag);
+            // The 16 fragment reads of tap + 1 are NOT issued as a burst in front of this tap's MFMAs: right after the
+            // barrier all 8 waves would queue 128 ds_read_b128 (512 LDS cycles, and a wave can have only 15 in flight)
+            // with the MFMAs stuck behind them in program order -- stamps: ~600 cycles per tap before the first MFMA.
+            // Each position block's 8 MFMAs go first, the reads of the next tap's same block (and one weight block) follow.
+            constexpr int S = decltype(cur_tag)::value;          // register sets of this tap's / the next tap's fragments
+            constexpr int N = decltype(nxt_tag)::value;
+            const int tn = tap + 1;
+            const int dt = tn / 9, dy = (tn / 3) % 3, dx = tn % 3;
+            const char* ws = wst + (tn % CD_WSTAGES) * CD_W_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[S][j][ks], af[S][i][ks], acc[i][j], 0, 0, 0);
+                if (tn < 27) {
+                    const int blk = wm * 4 + i;                                  // (t, y) row of the tile
+                    const int row = (((blk >> 3) + dt) * CD_HY + ((blk & 7) + dy)) * CD_HX + dx + frow;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        af[N][i][ks] = *(const bf16x8*)(halo + row * 128 + (((fchunk + 4 * ks) ^ (row & 7)) << 4));
+                        bfr[N][i][ks] = *(const bf16x8*)(ws + (b_off[i] ^ (ks << 6)));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            CSTAMP(7);                                           // [7] MFMAs with the next tap's reads in their shadow
         }
-        sync_all();
+        sync_all(pf);
     };
 
     const int nchunks = p.Cin >> 6;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * 64;
-        load_halo(c0);
+        CSTAMP(3);
+        load_halo(c0, ch == 0 ? 0 : Q_PLANE1);                  // (planes 0 and 1 of a later chunk arrived under the previous one)
         load_w(0, 0, c0);
         load_w(1, 1, c0);
-        sync_all();
+        CSTAMP(4);                                               // [4] issue of a chunk's halo + first weights
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        CSTAMP(5);                                               // [5] ... until they have landed everywhere
         if (active) read_frags(s0_t{}, 0);
-        for (int tap = 0; tap < 26; tap += 2) {
-            tap_body(tap, c0, s0_t{}, s1_t{});
-            tap_body(tap + 1, c0, s1_t{}, s0_t{});
+        const int c_next = ch + 1 < nchunks ? c0 + 64 : -1;
+        // all 27 taps unrolled: the tap's halo offset (dt, dy, dx), its weight stage and its share of the halo prefetch
+        // become constants -- no scalar arithmetic or branching between a barrier and the first MFMA behind it
+for (int tap = 0; tap < 26; tap += 2) {
+            tap_body(tap, c0, c_next, s0_t{}, s1_t{});
+            tap_body(tap + 1, c0, c_next, s1_t{}, s0_t{});
         }
-        tap_body(26, c0, s0_t{}, s1_t{});
+        tap_body(26, c0, c_next, s0_t{}, s1_t{});
     }
 
     // ---- epilogue: bias (+ add), bf16, through a 4 KB per-wave LDS scratch (the halo is free after the last
     // barrier) so that every store instruction writes whole 128-byte rows (16 bytes per lane)
+    CSTAMP(3);
+#ifdef LTXMI_CONV_STAMPS
+    if (g_conv_stamps && lane == 0 && blockIdx.x < 256) {
+        // (the first 256 workgroups = the first round) [7] = everything between taps and chunks is in [3]
+        unsigned long long* o = g_conv_stamps + (blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 8; ++i) o[i] = cst_acc[i];
+    }
+#endif
     if (!active) return;                                   // (the last barrier of the tap loop is behind every wave)
     char* scr = smem + wave * 4096;
     const int ecol = (lane >> 4) * 4;
@@ -230,12 +340,22 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     }
 }
 
+}  // namespace ltxmi
+#ifdef LTXMI_CONV_STAMPS
+extern "C" int ltxmi_debug_set_conv_stamps(void* buf) {
+    unsigned long long* b = (unsigned long long*)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(ltxmi::g_conv_stamps), &b, sizeof(b));
+}
+#endif
+namespace ltxmi {
+
 // Returns -1 when the shape is not one this kernel takes (the caller then uses the implicit GEMM).
 int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     const int st = a->stride_t > 0 ? a->stride_t : 1, sh = a->stride_hw > 0 ? a->stride_hw : 1;
     const int kt = a->kernel_t > 0 ? a->kernel_t : 3;
     if (st != 1 || sh != 1 || kt != 3 || a->out_T > 0 || a->tpad > 0) return -1;
     if (a->Cin % 64 != 0 || a->Cout % 8 != 0 || !a->bias) return -1;
+    if ((int64_t)a->B * a->T * a->H * a->W * a->Cin * 2 >= 0x7ffffff0ll) return -1;   // halo rows are addressed with 32-bit byte offsets
     if (a->d2s && (a->Cout % 1024 != 0 || a->add)) return -1;          // a 128-column block must be one (p1 p2 p3)
     ConvDirectP p;
     p.x = (const uint16_t*)a->x; p.w = (const uint16_t*)a->w; p.bias = (const uint16_t*)a->bias;
