@@ -74,9 +74,11 @@ struct Lane {
 // One segment: VALU = softmax of X's pending scores (X.s -> X.pf, X.m, rescale of X.o / X.l);
 // matrix pipe = Y's row sums and PV with Y's pending P against the V slot `vs`, and Y's next
 // scores against the K slot `ks`.
-template <bool TAIL>
+// hook(j) runs once per chunk j, right behind the chunk's MFMA: the kernel uses it to issue its LDS-DMA pieces one at a
+// time in the shadow of an MFMA instead of as a burst of four behind the barrier
+template <bool TAIL, typename Hook>
 __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const char* vs, const Lane& L,
-                                        const bf16x8& ones, float c, int key0, int Lk, Stamps& st, int st0) {
+                                        const bf16x8& ones, float c, int key0, int Lk, Stamps& st, int st0, Hook&& hook) {
     // ---- head: K fragments of the whole slot (8 x ds_read_b128), Y's row sums, X's row max
     bf16x8 kf[8];
 #pragma unroll
@@ -151,6 +153,7 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
             const int jj = j - 8, sp = jj >> 1, d = jj & 1;
             Y.o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jj], __builtin_bit_cast(bf16x8, Y.pf[sp]), Y.o[d], 0, 0, 0);
         }
+        hook(j);
         // softmax of two scores; the pair is packed one chunk later (a v_cvt_pk right behind the v_exp
         // it reads costs an s_nop: transcendental -> VALU hazard)
         const int kb = j >> 3, e0 = 2 * (j & 7);
@@ -239,6 +242,27 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
             : "=&s"(keep)
             : "v"(voff0), "v"(voff1), "s"(lds_addr), "s"(desc)
             : "memory", "scc");
+    };
+    auto dma1 = [&](const u32x4& desc, uint32_t lds_addr, uint32_t voff) {
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(lds_addr), "s"(desc)
+            : "memory");
+    };
+    // piece i (0 / 1) of this wave's share of K tile t / V tile t
+    auto dma_k1 = [&](int t, int i) {
+        const uint32_t dst = lds0 + (uint32_t)((t & (RING - 1)) * TILE_BYTES + (2 * wave + i) * 1024);
+        dma1(k_desc, dst, k_voff[i] + (uint32_t)t * k_tile_step);
+    };
+    auto dma_v1 = [&](int t, int i) {
+        const uint32_t dst = lds0 + (uint32_t)((RING + (t & (RING - 1))) * TILE_BYTES + (2 * wave + i) * 1024);
+        dma1(v_desc, dst, v_voff[i] + (uint32_t)t * v_tile_step);
     };
     auto dma_k = [&](int t) {
         const uint32_t dst = lds0 + (uint32_t)((t & (RING - 1)) * TILE_BYTES + 2 * wave * 1024);
@@ -363,11 +387,14 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         STAMP(0);
-        dma_k(t + 3);
-        dma_v(t + 2);
         STAMP(1);
-        segment<TAIL>(A, Bk, kring + (t & 3) * TILE_BYTES, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2);
-        segment<TAIL>(Bk, A, kring + ((t + 1) & 3) * TILE_BYTES, vring + (t & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 4);
+        // this iteration's four LDS-DMA pieces -- K(t+3) into the slot K(t-1) left at this barrier, V(t+2) into V(t-2)'s --
+        // go out one at a time behind an MFMA (chunks 3 and 11 of each segment), in this order (the counted wait below
+        // relies on it): a burst of four behind the barrier cost ~200 cycles per iteration with the wave issuing nothing else
+        segment<TAIL>(A, Bk, kring + (t & 3) * TILE_BYTES, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2,
+                      [&](int j) { if (j == 3) dma_k1(t + 3, 0); else if (j == 11) dma_k1(t + 3, 1); });
+        segment<TAIL>(Bk, A, kring + ((t + 1) & 3) * TILE_BYTES, vring + (t & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 4,
+                      [&](int j) { if (j == 3) dma_v1(t + 2, 0); else if (j == 11) dma_v1(t + 2, 1); });
         // everything issued before this iteration's four pieces has landed: K(t+2), V(t+1)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
