@@ -329,6 +329,12 @@ int ltxmi_groupnorm_silu_bf16(const void* x, void* y, const void* residual, int3
                               float* workspace, void* stream);
 int ltxmi_pixel_shuffle2d_ndhwc_bf16(const void* x, void* y, int64_t frames, int32_t H, int32_t W, int32_t C,
                                      void* stream);
+/* Tile cross-fade of the tiled VAE decode / encode (blend_z / blend_v / blend_h, vae.py:193-221), in place in b:
+ *   b[o, z, i] = a[o, len_a - extent + z, i] * (1 - z / extent) + b[o, z, i] * (z / extent),   z < extent,
+ * both tensors contiguous and viewed as [outer][len][inner] around the blended axis; dtype: 0 fp32, 1 bf16, 2 fp16 (the
+ * reference keeps z-tiles in fp16, vae.py:388). */
+int ltxmi_tile_blend(const void* a, void* b, int32_t dtype, int64_t outer, int64_t len_a, int64_t len_b,
+                     int64_t inner, int32_t extent, void* stream);
 int ltxmi_adain_filter(const void* latents, const void* reference, void* out, int32_t is_bf16, int32_t planes,
                        int64_t n, int64_t n_ref, float factor, void* stream);
 

@@ -121,6 +121,8 @@ template <> __device__ __forceinline__ float ld<float>(const float* p, int64_t i
 template <> __device__ __forceinline__ float ld<uint16_t>(const uint16_t* p, int64_t i) { return bf2f(p[i]); }
 __device__ __forceinline__ void st(float* p, int64_t i, float v) { p[i] = v; }
 __device__ __forceinline__ void st(uint16_t* p, int64_t i, float v) { p[i] = f2bf(v); }
+template <> __device__ __forceinline__ float ld<_Float16>(const _Float16* p, int64_t i) { return (float)p[i]; }
+__device__ __forceinline__ void st(_Float16* p, int64_t i, float v) { p[i] = (_Float16)v; }
 
 __device__ __forceinline__ void block_sum2(float& a, float& b) {
     __shared__ float red[2][UP_THREADS / 64];
@@ -157,6 +159,23 @@ __global__ void adain_kernel(const T* __restrict__ x, const T* __restrict__ ref,
         const float v = ld(xp, i);
         const float tform = (v - mx) * scale + mr;
         st(op, i, v + factor * (tform - v));
+    }
+}
+
+// Tile cross-fade of the tiled VAE paths: b[o, z, i] = a[o, La - extent + z, i] * (1 - z / extent) + b[o, z, i] * (z / extent)
+// for z < extent, with both tensors viewed as [outer][L][inner] around the blended axis (vae.py:193-221 blend_z / _v / _h).
+template <typename T>
+__global__ void tile_blend_kernel(const T* __restrict__ a, T* __restrict__ b, int64_t outer, int64_t La, int64_t Lb,
+                                  int64_t inner, int extent) {
+    const int64_t total = outer * extent * inner;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx % inner, r = idx / inner;
+        const int z = (int)(r % extent);
+        const int64_t o = r / extent;
+        const float w = (float)z / (float)extent;
+        const int64_t ia = (o * La + (La - extent + z)) * inner + i, ib = (o * Lb + z) * inner + i;
+        const float va = ld(a, ia), vb = ld(b, ib);
+        st(b, ib, va * (1.0f - w) + vb * w);
     }
 }
 
@@ -213,6 +232,27 @@ extern "C" int ltxmi_pixel_shuffle2d_ndhwc_bf16(const void* x, void* y, int64_t 
     hipLaunchKernelGGL(pixel_shuffle2d_kernel, dim3((unsigned)g), dim3(UP_THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)x, (uint16_t*)y, H, W, C, chunks);
     return check_launch("ltxmi_pixel_shuffle2d_ndhwc_bf16");
+}
+
+extern "C" int ltxmi_tile_blend(const void* a, void* b, int32_t dtype, int64_t outer, int64_t len_a, int64_t len_b,
+                                int64_t inner, int32_t extent, void* stream) {
+    LTXMI_REQUIRE(dtype >= 0 && dtype <= 2, LTXMI_ERR_INVALID_ARG, "ltxmi_tile_blend: dtype %d not in {0 fp32, 1 bf16, 2 fp16}", dtype);
+    LTXMI_REQUIRE(a && b, LTXMI_ERR_INVALID_ARG, "ltxmi_tile_blend: NULL argument");
+    LTXMI_REQUIRE(outer > 0 && inner > 0 && extent > 0 && extent <= len_a && extent <= len_b, LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_tile_blend: need outer, inner > 0 and 0 < extent <= both lengths (got %d, %lld, %lld)", extent,
+                  (long long)len_a, (long long)len_b);
+    const int64_t total = outer * extent * inner;
+    const int grid = (int)((total + UP_THREADS - 1) / UP_THREADS < 65535 ? (total + UP_THREADS - 1) / UP_THREADS : 65535);
+    if (dtype == 1)
+        hipLaunchKernelGGL(tile_blend_kernel<uint16_t>, dim3(grid), dim3(UP_THREADS), 0, (hipStream_t)stream,
+                           (const uint16_t*)a, (uint16_t*)b, outer, len_a, len_b, inner, extent);
+    else if (dtype == 2)
+        hipLaunchKernelGGL(tile_blend_kernel<_Float16>, dim3(grid), dim3(UP_THREADS), 0, (hipStream_t)stream,
+                           (const _Float16*)a, (_Float16*)b, outer, len_a, len_b, inner, extent);
+    else
+        hipLaunchKernelGGL(tile_blend_kernel<float>, dim3(grid), dim3(UP_THREADS), 0, (hipStream_t)stream,
+                           (const float*)a, (float*)b, outer, len_a, len_b, inner, extent);
+    return check_launch("ltxmi_tile_blend");
 }
 
 extern "C" int ltxmi_adain_filter(const void* latents, const void* reference, void* out, int32_t is_bf16,

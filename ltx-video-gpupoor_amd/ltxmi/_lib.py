@@ -82,6 +82,7 @@ SIGNATURES = {
                                           c_void_p, c_float, c_void_p, c_void_p]),
     "ltxmi_pixel_shuffle2d_ndhwc_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "ltxmi_adain_filter": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_float, c_void_p]),
+    "ltxmi_tile_blend": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "ltxmi_patchify_to_ndhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                              c_void_p]),
     "ltxmi_space_to_depth_skip_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

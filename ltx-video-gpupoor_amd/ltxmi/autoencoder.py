@@ -668,7 +668,7 @@ class CausalVideoAutoencoder(nn.Module):
                 tile = z[:, :, i:i + ts + 1]
                 tile = self._hw_tiled_encode(tile) if self.use_hw_tiling else self._cat_moments(self._encode(tile))
                 if i > 0:
-                    tile = tile[:, :, 1:]
+                    tile = tile[:, :, 1:].contiguous()          # (the blend kernel writes into it in place)
                 row.append(tile)
             result = []
             for i, tile in enumerate(row):
@@ -702,19 +702,13 @@ class CausalVideoAutoencoder(nn.Module):
 
     @staticmethod
     def _blend(a, b, extent, dim):
-        """blend_z / blend_v / blend_h (vae.py:193-221): linear cross-fade of the overlap, written
-        into ``b``.  One fused lerp over the overlap instead of the reference's per-slice loop."""
-        extent = min(a.shape[dim], b.shape[dim], extent)
-        if extent <= 0:
-            return b
-        w = (torch.arange(extent, device=b.device, dtype=torch.float32) / extent)
-        shape = [1] * b.dim()
-        shape[dim] = extent
-        w = w.view(shape)
-        sa = a.narrow(dim, a.shape[dim] - extent, extent).float()
-        sb = b.narrow(dim, 0, extent)
-        sb.copy_((sa * (1 - w) + sb.float() * w).to(b.dtype))
-        return b
+        """blend_z / blend_v / blend_h (vae.py:193-221): linear cross-fade of the overlap, written into ``b`` -- one kernel
+        over the overlap (``ltxmi_tile_blend``) instead of the reference's per-slice loop."""
+        if a.dtype != b.dtype:
+            a = a.to(b.dtype)
+        if not b.is_contiguous():
+            raise ValueError("tile blend: the tile written to must be contiguous")
+        return ops.tile_blend_(a.contiguous(), b, extent, dim)
 
     def _hw_tiled_decode(self, z, target_shape, timestep=None, stats=None):      # vae.py:223-263
         overlap_size = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
@@ -761,7 +755,7 @@ class CausalVideoAutoencoder(nn.Module):
                 d = dec(z[:, :, i:i + tl + 1])
                 if i > 0:
                     d = d[:, :, 1:]
-                row.append(d.to(torch.float16))
+                row.append(d.to(torch.float16).contiguous())
             result = []
             for i, tile in enumerate(row):
                 if i > 0:

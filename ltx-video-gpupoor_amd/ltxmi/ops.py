@@ -505,3 +505,29 @@ def adain_filter(latents, reference, factor=1.0):
                                  latents.numel() // planes, reference.numel() // planes, float(factor), _stream()),
           "ltxmi_adain_filter")
     return out
+
+
+def tile_blend_(a, b, extent, dim):
+    """In place in ``b``: the first ``extent`` slices of ``b`` along ``dim`` cross-faded with the last ``extent`` of ``a``
+    (blend_z / blend_v / blend_h, vae.py:193-221).  a, b: contiguous, same dtype (fp32 or bf16), equal sizes on every
+    other axis."""
+    codes = {torch.float32: 0, BF16: 1, torch.float16: 2}
+    if a.dtype != b.dtype or b.dtype not in codes:
+        raise TypeError("ltxmi.tile_blend_: fp32, bf16 or fp16 tensors of the same dtype expected")
+    if not (a.is_contiguous() and b.is_contiguous()):
+        raise ValueError("ltxmi.tile_blend_: contiguous tensors expected")
+    sa, sb = list(a.shape), list(b.shape)
+    if len(sa) != len(sb) or sa[:dim] + sa[dim + 1:] != sb[:dim] + sb[dim + 1:]:
+        raise ValueError("ltxmi.tile_blend_: shapes differ off the blended axis")
+    extent = min(sa[dim], sb[dim], int(extent))
+    if extent <= 0:
+        return b
+    outer = 1
+    for n in sb[:dim]:
+        outer *= n
+    inner = 1
+    for n in sb[dim + 1:]:
+        inner *= n
+    check(lib.ltxmi_tile_blend(_ptr(a), _ptr(b), codes[b.dtype], outer, sa[dim], sb[dim], inner, extent, _stream()),
+          "ltxmi_tile_blend")
+    return b

@@ -191,6 +191,10 @@ int main() {
     expect_fail(ltxmi_pixel_shuffle2d_ndhwc_bf16(p, p, 2, 16, 16, 2048, nullptr), "pixel_shuffle(no device)");
     expect_fail(ltxmi_adain_filter(p, p, p, 1, 128, 2 * 16 * 16, 1 * 8 * 8, 1.0f, nullptr), "adain(no device)");
     expect_fail(ltxmi_adain_filter(p, nullptr, p, 1, 128, 2 * 16 * 16, 1 * 8 * 8, 1.0f, nullptr), "adain(NULL)");
+    expect_fail(ltxmi_tile_blend(p, p, 2, 3 * 97, 512, 512, 768, 128, nullptr), "tile_blend(no device)");
+    expect_fail(ltxmi_tile_blend(p, p, 1, 3 * 97, 512, 100, 768, 128, nullptr), "tile_blend(extent > length)");
+    expect_fail(ltxmi_tile_blend(p, p, 3, 3 * 97, 512, 512, 768, 128, nullptr), "tile_blend(bad dtype)");
+    expect_fail(ltxmi_tile_blend(nullptr, p, 1, 3 * 97, 512, 512, 768, 128, nullptr), "tile_blend(NULL)");
 
     printf("abi_host_asan: %d calls, %d unexpected\n", g_calls, g_bad);
     return g_bad ? 1 : 0;

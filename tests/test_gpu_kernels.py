@@ -972,3 +972,34 @@ def test_gemm_k_blocked_operand(M, N, K, P, epi):
         want = ops.gemm(a, w, b)
         got = ops.gemm(blocked[0], w, b, a_kblock=K // P, a_kblock_stride=M * (K // P))
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("dim,extent", [(2, 16), (3, 128), (4, 96), (2, 500)])
+def test_tile_blend(dtype, dim, extent):
+    """blend_z / blend_v / blend_h (vae.py:193-221) in one kernel, in place in b: against the reference's formula slice by
+    slice (fp32 arithmetic, one rounding), for the three dtypes tiles have on the tiled paths; an extent larger than a
+    tensor is clipped as in the reference."""
+    from ltxmi import ops
+    g = torch.Generator().manual_seed(210)
+    shape_a = [1, 3, 40, 160, 192]
+    shape_b = list(shape_a)
+    shape_b[dim] -= 7                                   # the two tiles may differ along the blended axis only
+    a = torch.randn(*shape_a, generator=g).to(dtype)
+    b = torch.randn(*shape_b, generator=g).to(dtype)
+    e = min(a.shape[dim], b.shape[dim], extent)
+    want = b.clone().float()
+    for z in range(e):
+        ia = [slice(None)] * 5
+        ib = [slice(None)] * 5
+        ia[dim] = a.shape[dim] - e + z
+        ib[dim] = z
+        want[tuple(ib)] = a[tuple(ia)].float() * (1 - z / e) + b[tuple(ib)].float() * (z / e)
+    bd = b.to(DEV)
+    out = ops.tile_blend_(a.to(DEV), bd, extent, dim)
+    assert out.data_ptr() == bd.data_ptr()
+    tol = dict(rtol=0, atol=0) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(out.float().cpu(), want.to(dtype).float(), **(dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else tol))
+    untouched = [slice(None)] * 5
+    untouched[dim] = slice(e, None)
+    assert torch.equal(out.cpu()[tuple(untouched)], b[tuple(untouched)])
