@@ -374,7 +374,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extras", action="store_true", help="skip the B_eff-1 / attention-shape / VAE / CPU legs")
     ap.add_argument("--parallelism", choices=["both", "replicas", "ulysses"], default="both",
                     help="N > 1 only.  replicas: every rank denoises its own video, no data-path collective (weak scaling, "
