@@ -281,6 +281,29 @@ def time_vae(device, iters, grid=GRID, z_tile=0):
     return out
 
 
+def time_vae_tile_parallel(device, iters, dist, grid=(33, 23, 40), z_tile=4):
+    """BASELINE config 5 over the ranks: the z-tiles of the tiled decode spread over the GPUs (tile n on rank n mod P,
+    broadcast, blends everywhere: ltxmi.distributed.tile_parallel_vae_decode).  MAX over ranks of the median."""
+    from ltxmi import distributed as sp
+    vae, z, ts = make_vae(device, grid, z_tile)
+    times = []
+    with torch.no_grad():
+        img = sp.tile_parallel_vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)
+        assert torch.isfinite(img.float()).all(), "non-finite tile-parallel VAE decode output"
+        for _ in range(iters):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            img = sp.tile_parallel_vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    dt = max_over_ranks(pct(times, 0.5), dist, device)
+    frames = img.shape[2]
+    return {"latent": [1, C_LAT] + list(grid), "frames": frames, "shape": list(img.shape), "z_tile": z_tile,
+            "tiles_over_ranks": dist.get_world_size(), "ms_per_decode": round(dt * 1e3, 2), "iters": iters,
+            "frames_per_s": round(frames / dt, 2)}
+
+
 def cpu_baseline():
     """The oracle's fp32 restatement of one transformer block (all three sub-layers) at the bench
     shape for ONE cond, on all host cores; a denoise step is 28 blocks x 3 conds (embeddings,
@@ -359,7 +382,16 @@ def _stage_collectives_through_host(dist):
         reduce(h, op=op, group=group, **kw)
         t.copy_(h)
 
-    dist.all_to_all_single, dist.all_gather, dist.all_reduce = all_to_all_single, all_gather, all_reduce
+    bcast = dist.broadcast
+
+    def broadcast(t, src=0, group=None, **kw):
+        if not t.is_cuda:
+            return bcast(t, src=src, group=group, **kw)
+        h = t.cpu()
+        bcast(h, src=src, group=group, **kw)
+        t.copy_(h)
+
+    dist.all_to_all_single, dist.all_gather, dist.all_reduce, dist.broadcast = all_to_all_single, all_gather, all_reduce, broadcast
 
 
 def max_over_ranks(x, dist, device):
@@ -548,6 +580,14 @@ def main():
                                "attention_launch_ms": round(uly["at_ms"], 4),
                                "note": "same step, tokens sharded N/P per rank, packed q,k,v all-to-all + o all-to-all per "
                                        "layer over RCCL, final all-gather (ltxmi/distributed.py)"}
+    if (world > 1 or args.rehearse_both) and args.parallelism == "both" and not args.no_extras:
+        # the VAE half of the metric over the ranks (every rank takes part: collective)
+        try:
+            vtp = time_vae_tile_parallel(device, 3, dist)
+        except Exception as e:  # noqa: BLE001
+            vtp = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if rank == 0:
+            line["vae_decode_config5_tile_parallel"] = vtp
     extras = (not args.no_extras) and world == 1 and not ulysses_only
     if extras:
         # B_eff = 1 (report both): the same model, the text row only

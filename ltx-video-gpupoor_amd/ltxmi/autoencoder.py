@@ -734,9 +734,11 @@ class CausalVideoAutoencoder(nn.Module):
         return torch.cat(result_rows, dim=3)
 
     def decode(self, z, return_dict: bool = True, target_shape=None, timestep: Optional[torch.Tensor] = None,
-               _stats=None):
+               _stats=None, _tile_owner=None):
         """vae.py:357-413.  With z-tiling the tiles are kept on the device (the reference's
-        ``.to(float16).cpu()`` per tile at :388 was a VRAM workaround); the result is fp16 as there."""
+        ``.to(float16).cpu()`` per tile at :388 was a VRAM workaround); the result is fp16 as there.
+        ``_tile_owner`` (extension, ltxmi.distributed.tile_parallel_vae_decode): ``(n, decode_fn) -> tile`` -- the z-tiles
+        are independent until the blends, so ranks can decode different tiles and exchange them."""
         assert target_shape is not None, "target_shape must be provided for decoding"
 
         def dec(t):
@@ -751,11 +753,13 @@ class CausalVideoAutoencoder(nn.Module):
             blend_extent = int(ts * 0.25)
             t_limit = ts - blend_extent
             row = []
-            for i in range(0, z.shape[2], overlap_size):
-                d = dec(z[:, :, i:i + tl + 1])
-                if i > 0:
-                    d = d[:, :, 1:]
-                row.append(d.to(torch.float16).contiguous())
+            for n, i in enumerate(range(0, z.shape[2], overlap_size)):
+                def one(i=i):
+                    d = dec(z[:, :, i:i + tl + 1])
+                    if i > 0:
+                        d = d[:, :, 1:]
+                    return d.to(torch.float16).contiguous()
+                row.append(one() if _tile_owner is None else _tile_owner(n, one))
             result = []
             for i, tile in enumerate(row):
                 if i > 0:
@@ -799,7 +803,7 @@ def vae_encode(media_items, vae: CausalVideoAutoencoder, split_size: int = 1, va
 
 
 def vae_decode(latents, vae: CausalVideoAutoencoder, is_video: bool = True, split_size: int = 1,
-               vae_per_channel_normalize=False, timestep=None):
+               vae_per_channel_normalize=False, timestep=None, _tile_owner=None):
     """vae_encode.py:94-165: un-normalise (per-channel std/mean, fused into the layout kernel)
     and decode.  latents [B,C,F,H,W]."""
     if split_size != 1:
@@ -815,4 +819,4 @@ def vae_decode(latents, vae: CausalVideoAutoencoder, is_video: bool = True, spli
             latents = latents / sf
     return vae.decode(latents.to(vae.dtype), return_dict=False,
                       target_shape=(1, 3, fl * ts if is_video else 1, hl * ss, wl * ss),
-                      timestep=timestep, _stats=stats)[0]
+                      timestep=timestep, _stats=stats, _tile_owner=_tile_owner)[0]

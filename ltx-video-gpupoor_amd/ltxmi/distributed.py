@@ -211,3 +211,32 @@ def usp_dit_forward(model, hidden_states, freqs_cis, encoder_hidden_states=None,
 class _Frozen:
     """Stand-in ``ltxv_model`` for the block loop under sequence parallelism: never interrupts mid-forward."""
     _interrupt = False
+
+
+# ------------------------------------------------------------------ VAE decode: z-tiles over the ranks
+def tile_parallel_vae_decode(latents, vae, is_video=True, vae_per_channel_normalize=False, timestep=None, group=None):
+    """``vae_decode`` with the z-tiles of the tiled decode (vae.py:365-402) spread over the ranks: tile n is decoded by
+    rank n mod P and broadcast (shape first, then the fp16 pixels); the cross-fades and the concatenation then run on
+    every rank, so every rank returns the full video -- the same bits as the single-rank tiled decode.  No collective
+    inside a convolution.  Falls back to the plain decode when z-tiling is off or the clip is a single tile."""
+    from .autoencoder import vae_decode
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = latents.device
+
+    def owner(n, decode_tile):
+        src = n % world
+        src_global = dist.get_global_rank(group, src) if group is not None else src
+        if src == rank:
+            tile = decode_tile()
+            shape = torch.tensor(list(tile.shape), device=dev, dtype=torch.int64)
+        else:
+            tile = None
+            shape = torch.zeros(5, device=dev, dtype=torch.int64)
+        dist.broadcast(shape, src=src_global, group=group)
+        if tile is None:
+            tile = torch.empty([int(v) for v in shape.tolist()], device=dev, dtype=torch.float16)
+        dist.broadcast(tile, src=src_global, group=group)
+        return tile
+
+    return vae_decode(latents, vae, is_video, vae_per_channel_normalize=vae_per_channel_normalize, timestep=timestep,
+                      _tile_owner=owner if world > 1 else None)

@@ -996,3 +996,66 @@ def test_ulysses_world2_real_kernels_on_one_gpu(per_token):
         p.join(timeout=60)
     for rank, status, err in results:
         assert status == "ok", f"rank {rank}:\n{status}"
+
+
+def _tile_parallel_decode_worker(rank, world, port, q):
+    import os
+    import sys
+    import traceback
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "ltx-video-gpupoor_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        bcast = dist.broadcast
+
+        def broadcast(t, src=0, group=None, **kw):                 # gloo moves host tensors: staged in the test worker
+            if not t.is_cuda:
+                return bcast(t, src=src, group=group, **kw)
+            h = t.cpu()
+            bcast(h, src=src, group=group, **kw)
+            t.copy_(h)
+        dist.broadcast = broadcast
+        import ltxmi
+        from ltxmi import distributed as sp
+        cfg, sd = vae_case("b", base=64)
+        v = build_vae(cfg, sd)
+        v.enable_z_tiling(4)
+        z = torch.randn(1, 128, 10, 2, 3, generator=torch.Generator().manual_seed(14)).to(BF).to(DEV)   # 4 z-tiles
+        ts = torch.tensor([0.05], device=DEV)
+        with torch.no_grad():
+            ref = ltxmi.vae_decode(z, v, True, vae_per_channel_normalize=True, timestep=ts)         # every tile on this rank
+            out = sp.tile_parallel_vae_decode(z, v, True, vae_per_channel_normalize=True, timestep=ts)
+        torch.cuda.synchronize()
+        assert out.shape == ref.shape == (1, 3, 73, 64, 96) and out.dtype == torch.float16
+        assert torch.equal(out, ref)
+        q.put((rank, "ok"))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        q.put((rank, traceback.format_exc()))
+
+
+def test_tile_parallel_vae_decode_world2_on_one_gpu():
+    """SURVEY 8e, VAE row: the z-tiles of a tiled decode spread over the ranks (tile n on rank n mod P, broadcast, blends on
+    every rank) -- world size 2, both ranks on the box's one GPU, gloo transport -- gives the single-rank tiled decode bit
+    for bit on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tile_parallel_decode_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status in results:
+        assert status == "ok", f"rank {rank}:\n{status}"
