@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic only: in-kernel s_memtime stamps of a stamped build of the persistent GEMM (-DLTXMI_GEMM_STAMPS, see
-gemm.hip) on the hot shapes, for the product kernel (algo 0: 8 waves of 128x64) and the one-wave-per-SIMD variant
-(algo 4: 4 waves of 128x128).
+gemm.hip) on the hot shapes, for the product kernel (algo 0: 8 waves of 128x64; round 2 also stamped experimental K loops
+through other algo values, see profiles/r02_gemm_ring_w4.log).
     make -C ltx-video-gpupoor_amd/csrc stamps && LTXMI_LIB=ltx-video-gpupoor_amd/ltxmi/libltxmi_stamp.so python tools/gemm_stamps.py"""
 import ctypes
 import os
@@ -18,7 +18,7 @@ buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
 _lib.lib.ltxmi_debug_set_gemm_stamps.restype = ctypes.c_int
 _lib.lib.ltxmi_debug_set_gemm_stamps.argtypes = [ctypes.c_void_p]
 assert _lib.lib.ltxmi_debug_set_gemm_stamps(buf.data_ptr()) == 0
-algos = [int(a) for a in sys.argv[1:]] or [0, 4]
+algos = [int(a) for a in sys.argv[1:]] or [0]
 for (M, N, K, epi, name) in [(14976, 8192, 2048, ops.EPI_GELU_TANH, "ff1"), (14976, 2048, 8192, ops.EPI_GATE_RESIDUAL, "ff2"),
                              (8192, 8192, 8192, ops.EPI_NONE, "8k^3")]:
     a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
