@@ -394,6 +394,52 @@ def _stage_collectives_through_host(dist):
     dist.all_to_all_single, dist.all_gather, dist.all_reduce, dist.broadcast = all_to_all_single, all_gather, all_reduce, broadcast
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher in the environment: run the driver's own N > 1 command
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`)
+    as a CHILD process and return its exit code.  Nothing in this process has touched the GPU (torch.cuda.device_count()
+    does not initialise it on this image), so no initialised process is ever replaced or forked.  A box with fewer GPUs
+    than ranks is refused (exit 2) unless LTXMI_BENCH_REHEARSAL=gloo: never an `n_gpus: 1` line for `--gpus N`."""
+    import socket
+    import subprocess
+    if not os.environ.get("LTXMI_BENCH_REHEARSAL") and "--selftest-launch" not in argv:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but this box shows {have} GPU(s); not running (set LTXMI_BENCH_REHEARSAL=gloo to "
+                  f"rehearse the control flow with the ranks sharing the visible GPUs)", file=sys.stderr)
+            return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd).returncode
+
+
+def selftest_launch(rank, world):
+    """What `--selftest-launch` runs in every rank: the rendezvous the launcher set up works, and rank 0 prints one line."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    ok = float(t.item()) == world * (world + 1) / 2 and dist.get_world_size() == world
+    if rank == 0:
+        print(json.dumps({"selftest_launch": bool(ok), "n_gpus": world}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def agree_failed(err, dist, device):
+    """a leg that failed on ONE rank (e.g. an allocation failure) must be abandoned by all of them together --
+    MAX all-reduce of a failure flag after the leg, so that nobody goes on to a collective the failing rank never joins."""
+    if dist is None:
+        return err is not None
+    t = torch.tensor([1 if err is not None else 0], device=device, dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
 def max_over_ranks(x, dist, device):
     if dist is None:
         return x
@@ -415,13 +461,24 @@ def main():
                          "the Ulysses run reported in the same line under \"ulysses\"")
     ap.add_argument("--rehearse-both", action="store_true",
                     help="run the N > 1 control flow (replicas, then Ulysses, both in the one JSON line) at world size 1")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="launcher check (CPU suite): every rank joins a gloo group, rank 0 prints {\"selftest_launch\": true, "
+                         "\"n_gpus\": world}; no GPU is touched")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE anything here touches the
+        # GPU (this process never initialises HIP; it only waits for its child and passes its exit code on)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line's n_gpus would not be what was asked for")
+    if args.selftest_launch:
+        return selftest_launch(rank, world)
     # Rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the build boxes have one): LTXMI_BENCH_REHEARSAL=gloo
     # lets the ranks share the visible GPUs and carries the collectives over gloo, staged through the host.  The numbers
     # of such a run mean nothing (the ranks time-share a GPU) and the line says so; what it checks is the code path.
@@ -488,19 +545,28 @@ def main():
         if (world > 1 or args.rehearse_both) and args.parallelism == "both":
             # the replicas measurement above is the line's `value`; a failure of the Ulysses mode (it could only be run
             # at world size 1 on hardware so far) must not take that number with it: it is reported instead
+            # (a failure inside a collective on one rank only still ends in the process group's timeout; what the flag
+            # agreed below covers is a rank that fails BETWEEN collectives -- allocation, a refused shape -- and would
+            # otherwise leave the others alone in the next leg)
+            err = None
             try:
                 runner.enable_ulysses()
                 uly = measure(True)
-            except Exception as e:  # noqa: BLE001  (symmetric failures only: every rank runs the same code)
-                uly = {"error": f"{type(e).__name__}: {e}"[:400]}
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"[:400]
+            if agree_failed(err, dist, device):
+                uly = {"error": err or "another rank failed in the Ulysses leg"}
             # BASELINE config 3, the workload the Ulysses mode is named for: 2B i2v 1216x704x121 = 16 x 22 x 38 = 13376
             # tokens, first latent frame conditioned (per-token timesteps), one video over the ranks
             if "error" not in uly:
+                err = None
                 try:
                     runner.set_grid(GRID_CONFIG3, image_conditioned=True)
                     uly3 = measure(True)
                 except Exception as e:  # noqa: BLE001
-                    uly3 = {"error": f"{type(e).__name__}: {e}"[:400]}
+                    err = f"{type(e).__name__}: {e}"[:400]
+                if agree_failed(err, dist, device):
+                    uly3 = {"error": err or "another rank failed in the Ulysses config-3 leg"}
                 runner.set_grid(GRID)
             runner.sp = None
     ms_per_step = r["elapsed"] / args.steps * 1e3

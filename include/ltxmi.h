@@ -16,7 +16,13 @@
  *     innermost dimension contiguous; "ld*" arguments are row strides in ELEMENTS;
  *   - return value: 0 = LTXMI_OK, negative = ltxmi_status; ltxmi_last_error() returns
  *     a thread-local message for the last failing call.  Unsupported shapes are an
- *     error -- there is no fallback path of any kind.
+ *     error -- there is no fallback path of any kind;
+ *   - argument structs (ltxmi_*_args) MUST be zero-initialised before the fields in use are
+ *     set (`ltxmi_gemm_args a = {0};` / memset): versions append optional fields at the tail
+ *     (0.2: rowsumsq*, a_kblock* of ltxmi_gemm_args; q_rowsumsq*, q_norm*, rope_*, o_segment*
+ *     of ltxmi_attn_args; 0.3: q_rstd*), and a zero there means "off".  A caller must be
+ *     rebuilt against the header of the library it loads.  An optional pointer that is NULL
+ *     switches its companion size / stride fields off whatever they hold.
  */
 #ifndef LTXMI_H
 #define LTXMI_H
@@ -183,6 +189,11 @@ int ltxmi_timestep_embedding_bf16(const float* t, void* out, int32_t n, int32_t 
  * a: [B, L, D] contiguous rows lda; v rows ldv; m fp32 [B]. */
 int ltxmi_stg_blend_bf16(void* a, int64_t lda, const void* v, int64_t ldv,
                          const float* m, int32_t B, int32_t L, int32_t D, void* stream);
+/* The same blend (attention.py:1127-1141) over a contiguous a [G, B, L, D] with v addressed by strides in elements:
+ * v(g, b, l, :) at v + g*v_stride_g + b*v_stride_b + l*v_stride_l.  One launch over the K-blocked receive buffer of the
+ * Ulysses return exchange ([P source ranks][B, N/P][D/P]; the reference's xfuser path has no STG and no counterpart). */
+int ltxmi_stg_blend_grouped_bf16(void* a, const void* v, int64_t v_stride_g, int64_t v_stride_b, int64_t v_stride_l,
+                                 const float* m, int32_t G, int32_t B, int32_t L, int32_t D, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * VAE decode kernels (channels-last NDHWC activations, bf16).

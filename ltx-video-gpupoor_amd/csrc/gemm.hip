@@ -937,7 +937,11 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     p.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
     p.tiles_m = p.tiles_n = 0;
     p.cB = p.cT = p.cH = p.cW = p.cCin = 1; p.oT = p.oH = p.oW = 1; p.sT = p.sHW = 1; p.tpad = 0; p.tzero = 0; p.pad_replicate = 0; p.res = nullptr; p.res_ch = 0;
-    p.sumsq = a->rowsumsq; p.sumsq_cols = a->rowsumsq_cols; p.sumsq_ld = a->rowsumsq_ld;
+    // without a rowsumsq pointer the cols / ld fields are NOT read: the plain epilogue runs on the row-sums instance and
+    // must see cols = 0 (its extra stores are then dropped) whatever a caller left in those fields
+    p.sumsq = a->rowsumsq;
+    p.sumsq_cols = a->rowsumsq ? a->rowsumsq_cols : 0;
+    p.sumsq_ld = a->rowsumsq ? a->rowsumsq_ld : 0;
     p.a_kblk = a->a_kblock; p.a_kblk_stride = a->a_kblock_stride;
     if (a->a_kblock) {
         LTXMI_REQUIRE(a->a_kblock > 0 && a->a_kblock % 64 == 0 && a->K % a->a_kblock == 0 && a->a_kblock_stride % 8 == 0 &&

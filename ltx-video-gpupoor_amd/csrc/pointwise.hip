@@ -71,6 +71,33 @@ __global__ void stg_blend_kernel(uint16_t* __restrict__ a, int64_t lda, const ui
     }
 }
 
+// The same blend over a contiguous a [G][B][L][D] against a v addressed by (group, batch, token) strides: the K-blocked
+// receive buffer of the Ulysses return exchange ([P source ranks][B Nl][D / P]) blended in ONE launch with the values /
+// the block input, whose channel block p of token (b, n) lies at p * v_sg + b * v_sb + n * v_sl.
+__global__ void stg_blend_grouped_kernel(uint16_t* __restrict__ a, const uint16_t* __restrict__ v, int64_t v_sg, int64_t v_sb,
+                                         int64_t v_sl, const float* __restrict__ m, int B, int L, int D, int64_t total_chunks) {
+    const int cpr = D >> 3;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_chunks;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;                       // (g, b, l)
+        const int ch = (int)(i % cpr);
+        const int l = (int)(row % L);
+        const int64_t gb = row / L;
+        const int b = (int)(gb % B);
+        const int64_t g = gb / B;
+        const float mm = m[b];
+        if (mm == 1.0f) continue;
+        uint16_t* ap = a + row * D + ch * 8;
+        const u32x4 u = *(const u32x4*)ap;
+        const u32x4 w = *(const u32x4*)(v + g * v_sg + b * v_sb + l * v_sl + ch * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = pack_bf16(bf_lo(u[k]) * mm + bf_lo(w[k]) * (1.f - mm), bf_hi(u[k]) * mm + bf_hi(w[k]) * (1.f - mm));
+        *(u32x4*)ap = o;
+    }
+}
+
 // z [B,C,T,H,W] bf16 -> y [B,T,H,W,C] bf16, optionally * std[c] + mean[c]
 __global__ void ncdhw_to_ndhwc_kernel(const uint16_t* __restrict__ z, uint16_t* __restrict__ y, int C, int64_t thw,
                                       int64_t total, const float* __restrict__ std, const float* __restrict__ mean) {
@@ -357,6 +384,19 @@ extern "C" int ltxmi_stg_blend_bf16(void* a, int64_t lda, const void* v, int64_t
     hipLaunchKernelGGL(stg_blend_kernel, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream, (uint16_t*)a,
                        lda, (const uint16_t*)v, ldv, m, L, D, total);
     return check_launch("ltxmi_stg_blend_bf16");
+}
+
+extern "C" int ltxmi_stg_blend_grouped_bf16(void* a, const void* v, int64_t v_stride_g, int64_t v_stride_b, int64_t v_stride_l,
+                                            const float* m, int32_t G, int32_t B, int32_t L, int32_t D, void* stream) {
+    LTXMI_REQUIRE(a && v && m, LTXMI_ERR_INVALID_ARG, "ltxmi_stg_blend_grouped_bf16: NULL argument");
+    LTXMI_REQUIRE(G > 0 && B > 0 && L > 0 && D > 0, LTXMI_ERR_INVALID_ARG, "ltxmi_stg_blend_grouped_bf16: non-positive size");
+    LTXMI_REQUIRE(D % 8 == 0 && v_stride_g % 8 == 0 && v_stride_b % 8 == 0 && v_stride_l % 8 == 0 &&
+                      (((uintptr_t)a | (uintptr_t)v) & 15) == 0,
+                  LTXMI_ERR_UNSUPPORTED, "ltxmi_stg_blend_grouped_bf16: D and strides must be multiples of 8, pointers 16-byte aligned");
+    const int64_t total = (int64_t)G * B * L * (D / 8);
+    hipLaunchKernelGGL(stg_blend_grouped_kernel, dim3(pw_grid(total)), dim3(PW_THREADS), 0, (hipStream_t)stream, (uint16_t*)a,
+                       (const uint16_t*)v, v_stride_g, v_stride_b, v_stride_l, m, B, L, D, total);
+    return check_launch("ltxmi_stg_blend_grouped_bf16");
 }
 
 extern "C" int ltxmi_ncdhw_to_ndhwc_bf16(const void* z, void* y, int32_t B, int32_t C, int32_t T, int32_t H,

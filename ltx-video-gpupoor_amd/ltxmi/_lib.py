@@ -63,6 +63,8 @@ SIGNATURES = {
     "ltxmi_silu_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ltxmi_timestep_embedding_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ltxmi_stg_blend_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ltxmi_stg_blend_grouped_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int,
+                                             c_void_p]),
     "ltxmi_conv3d_ndhwc_bf16": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
     "ltxmi_pixelnorm_ada_silu_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                               c_int, c_float, c_void_p]),

@@ -147,10 +147,13 @@ class Attention(nn.Module):
     # ---- packed projection weights (product-side layout; built lazily, rebuilt when a source changes)
     def _pack(self, slot, mods):
         """Contiguous [sum(out), in] weight (and bias) of ``mods``, cached per slot.  The key holds storage AND version
-        of every source tensor, so an in-place edit (a LoRA merge, ``weight.copy_``, ``+=``) rebuilds the pack just like
-        a reload does; the caches that derive from it (the per-layer text K/V) key on the pack and follow."""
+        counter of every source tensor, so an in-place edit that autograd sees (``weight.copy_``, ``+=``, ``add_`` --
+        what a LoRA merge does) rebuilds the pack just like a reload does; the caches that derive from it (the
+        per-layer text K/V) key on the pack and follow.  NOT seen: edits through ``weight.data`` (no counter is
+        bumped) and any edit of an inference tensor (it has no counter, ``ops.tensor_version``): call
+        ``invalidate_packed()`` after those."""
         srcs = [t for m in mods for t in (m.weight, m.bias) if t is not None]
-        key = tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in srcs)
+        key = tuple((t.data_ptr(), ops.tensor_version(t), t.dtype, t.device) for t in srcs)
         hit = self._packs.get(slot)
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -274,8 +277,8 @@ class AttnProcessor2_0:
             # (same kernels on the same inputs: identical values).  Keyed on storage + version of the inputs;
             # the source tensors are kept alive so an address cannot be reused while the entry exists.
             ehs = encoder_hidden_states
-            key = (ehs.data_ptr(), tuple(ehs.shape), ehs._version, wkv.data_ptr(), wkv._version,
-                   attn.k_norm.weight.data_ptr(), attn.k_norm.weight._version)
+            key = (ehs.data_ptr(), tuple(ehs.shape), ops.tensor_version(ehs), wkv.data_ptr(), ops.tensor_version(wkv),
+                   attn.k_norm.weight.data_ptr(), ops.tensor_version(attn.k_norm.weight))
             cache = attn.__dict__.setdefault("_text_kv_cache", {})
             hit = cache.get(key) if ops.STEP_INVARIANT_CACHING else None
             if hit is None:

@@ -29,7 +29,7 @@ def _key_bias_from_mask(attention_mask, B, Lk):
                 f"(mask dim {d} has size {m.shape[d]} with stride {m.stride(d)})")
     # every block of a forward passes the same mask: keep its fp32 form (one conversion kernel per
     # forward instead of one per layer); keyed on storage + version so an in-place edit invalidates it
-    key = (m.data_ptr(), tuple(m.shape), tuple(m.stride()), m.dtype, m._version)
+    key = (m.data_ptr(), tuple(m.shape), tuple(m.stride()), m.dtype, ops.tensor_version(m))
     global _BIAS_CACHE
     if _BIAS_CACHE is None or _BIAS_CACHE[0] != key:
         _BIAS_CACHE = (key, m[:, 0, 0, :].to(torch.float32).contiguous(), m)     # m kept alive: no pointer reuse
@@ -47,6 +47,10 @@ def pay_attention(qkv_list, dropout_p=0., softmax_scale=None, causal=False, wind
     RMS-normalised (+ rotated) by the kernel while it loads it -- see ops.attention."""
     q, k, v = qkv_list
     qkv_list.clear()
+    if (q_norm is not None or rope is not None) and (q_lens is not None or k_lens is not None):
+        # checked before ANY branch below: the var-k-len path re-enters this function per chunk without q_norm / rope
+        # and would attend the raw projection un-normalised and un-rotated
+        raise NotImplementedError("pay_attention: q_norm / rope on load with q_lens / k_lens")
     if causal or tuple(window_size) != (-1, -1) or dropout_p != 0.:
         raise NotImplementedError("pay_attention: causal / windowed / dropout attention is not on this path")
     if force_attention not in (None, "sdpa"):
@@ -88,8 +92,6 @@ def pay_attention(qkv_list, dropout_p=0., softmax_scale=None, causal=False, wind
         q, k, v = q[:, :szq], k[:, :szk], v[:, :szk]
 
     bias = None if attention_mask is None else _key_bias_from_mask(attention_mask, b, k.size(1))
-    if q_norm is not None and (q_lens is not None or k_lens is not None):
-        raise NotImplementedError("pay_attention: q_norm on load with q_lens / k_lens")
     x = ops.attention(q, k, v, key_bias=bias, softmax_scale=softmax_scale, q_norm=q_norm, rope=rope)
     x = x.type(out_dtype)
     if final_padding > 0:

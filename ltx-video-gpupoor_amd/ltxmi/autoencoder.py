@@ -116,9 +116,10 @@ class CausalConv3d(nn.Module):
 
     def packed(self, d2s=False):
         """[Cout, 27*Cin] tap-major bf16 (+ rows re-ordered (p1 p2 p3, c') for the depth-to-space store)."""
-        # storage AND version of the sources: an in-place weight edit rebuilds the pack, as a reload does
+        # storage AND version counter of the sources: an in-place weight edit rebuilds the pack, as a reload does
+        # (edits through ``.data`` or of inference tensors bump no counter: call invalidate_packed() after those)
         wt, bs = self.conv.weight, self.conv.bias
-        key = (wt.data_ptr(), wt._version, None if bs is None else (bs.data_ptr(), bs._version), d2s)
+        key = (wt.data_ptr(), ops.tensor_version(wt), None if bs is None else (bs.data_ptr(), ops.tensor_version(bs)), d2s)
         if self._packed is None or self._packed[0] != key:
             with torch.no_grad():
                 w = self.conv.weight.permute(0, 2, 3, 4, 1)                  # [Cout, 3,3,3, Cin]
@@ -134,6 +135,10 @@ class CausalConv3d(nn.Module):
                     b = b.view(cp, 8).transpose(0, 1).reshape(-1)
                 self._packed = (key, w.contiguous().to(BF16), b.contiguous().to(BF16))
         return self._packed[1], self._packed[2]
+
+    def invalidate_packed(self):
+        """Drop the packed copy (rebuilt on the next forward); needed after edits the key cannot see (``.data``)."""
+        self._packed = None
 
     def _apply(self, fn, *a, **k):
         self._packed = None
@@ -733,12 +738,30 @@ class CausalVideoAutoencoder(nn.Module):
             result_rows.append(torch.cat(result_row, dim=4))
         return torch.cat(result_rows, dim=3)
 
+    def _hw_tiled_extent(self, n_latent):
+        """Pixels ``_hw_tiled_decode`` returns along an axis of ``n_latent`` latent positions (every tile cropped to
+        ``row_limit`` before the concatenation, vae.py:249-262)."""
+        ss = self.spatial_downscale_factor
+        stride = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
+        row_limit = self.tile_sample_min_size - int(self.tile_sample_min_size * self.tile_overlap_factor)
+        return sum(min(min(self.tile_latent_min_size, n_latent - i) * ss, row_limit) for i in range(0, n_latent, stride))
+
+    def _decoded_tile_shape(self, zshape, drop_first):
+        """Shape of one decoded z-tile, from its latent slice alone (so that ranks that did not decode it can allocate
+        it without being told): [B, 3, 8 (L - 1) + 1 (- 1 for the dropped frame), 32 H, 32 W]."""
+        B, _, L, H, W = zshape
+        frames = (L - 1) * self.temporal_downscale_factor + 1 - (1 if drop_first else 0)
+        ss = self.spatial_downscale_factor
+        hw = (self._hw_tiled_extent(H), self._hw_tiled_extent(W)) if self.use_hw_tiling else (H * ss, W * ss)
+        return (B, self.decoder.out_channels_rgb, frames) + hw
+
     def decode(self, z, return_dict: bool = True, target_shape=None, timestep: Optional[torch.Tensor] = None,
-               _stats=None, _tile_owner=None):
+               _stats=None, _tile_exchange=None):
         """vae.py:357-413.  With z-tiling the tiles are kept on the device (the reference's
         ``.to(float16).cpu()`` per tile at :388 was a VRAM workaround); the result is fp16 as there.
-        ``_tile_owner`` (extension, ltxmi.distributed.tile_parallel_vae_decode): ``(n, decode_fn) -> tile`` -- the z-tiles
-        are independent until the blends, so ranks can decode different tiles and exchange them."""
+        ``_tile_exchange`` (extension, ltxmi.distributed.tile_parallel_vae_decode): ``(decoders, shapes) -> tiles`` -- the
+        z-tiles are independent until the blends, so ranks can decode different tiles and exchange them;
+        ``decoders[n](out)`` writes tile n (fp16, ``shapes[n]``) into ``out``."""
         assert target_shape is not None, "target_shape must be provided for decoding"
 
         def dec(t):
@@ -752,21 +775,31 @@ class CausalVideoAutoencoder(nn.Module):
             overlap_size = int(tl * 0.75)
             blend_extent = int(ts * 0.25)
             t_limit = ts - blend_extent
-            row = []
-            for n, i in enumerate(range(0, z.shape[2], overlap_size)):
-                def one(i=i):
-                    d = dec(z[:, :, i:i + tl + 1])
-                    if i > 0:
-                        d = d[:, :, 1:]
-                    return d.to(torch.float16).contiguous()
-                row.append(one() if _tile_owner is None else _tile_owner(n, one))
-            result = []
-            for i, tile in enumerate(row):
+            starts = list(range(0, z.shape[2], overlap_size))
+
+            def tile(i, out=None):
+                d = dec(z[:, :, i:i + tl + 1])
                 if i > 0:
-                    tile = self._blend(row[i - 1], tile, blend_extent, 2)
-                    result.append(tile[:, :, :t_limit])
+                    d = d[:, :, 1:]
+                if out is None:
+                    return d.to(torch.float16).contiguous()
+                if tuple(out.shape) != tuple(d.shape):
+                    raise RuntimeError(f"tiled decode: tile at latent frame {i} is {tuple(d.shape)}, predicted {tuple(out.shape)}")
+                out.copy_(d)
+                return out
+
+            if _tile_exchange is None:
+                row = [tile(i) for i in starts]
+            else:
+                shapes = [self._decoded_tile_shape(z[:, :, i:i + tl + 1].shape, i > 0) for i in starts]
+                row = _tile_exchange([(lambda out, i=i: tile(i, out)) for i in starts], shapes)
+            result = []
+            for i, t in enumerate(row):
+                if i > 0:
+                    t = self._blend(row[i - 1], t, blend_extent, 2)
+                    result.append(t[:, :, :t_limit])
                 else:
-                    result.append(tile[:, :, :t_limit + 1])
+                    result.append(t[:, :, :t_limit + 1])
             decoded = torch.cat(result, dim=2)
         else:
             decoded = dec(z)
@@ -803,7 +836,7 @@ def vae_encode(media_items, vae: CausalVideoAutoencoder, split_size: int = 1, va
 
 
 def vae_decode(latents, vae: CausalVideoAutoencoder, is_video: bool = True, split_size: int = 1,
-               vae_per_channel_normalize=False, timestep=None, _tile_owner=None):
+               vae_per_channel_normalize=False, timestep=None, _tile_exchange=None):
     """vae_encode.py:94-165: un-normalise (per-channel std/mean, fused into the layout kernel)
     and decode.  latents [B,C,F,H,W]."""
     if split_size != 1:
@@ -819,4 +852,4 @@ def vae_decode(latents, vae: CausalVideoAutoencoder, is_video: bool = True, spli
             latents = latents / sf
     return vae.decode(latents.to(vae.dtype), return_dict=False,
                       target_shape=(1, 3, fl * ts if is_video else 1, hl * ss, wl * ss),
-                      timestep=timestep, _stats=stats, _tile_owner=_tile_owner)[0]
+                      timestep=timestep, _stats=stats, _tile_exchange=_tile_exchange)[0]

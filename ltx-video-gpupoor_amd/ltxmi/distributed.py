@@ -18,6 +18,7 @@ provides the same two entry points for the LTX DiT, written directly on ``torch.
 
 Requires H % P == 0 and N % P == 0 (and, for per-frame timesteps, whole frames per rank).
 """
+import math
 from typing import Callable, Optional
 
 import torch
@@ -36,11 +37,20 @@ def shard_tokens(x, rank, world, dim=1):
 
 
 def gather_tokens(x, group=None, dim=1):
-    """all_gather along the token axis (xdit_context_parallel.py:142)."""
+    """all_gather along the token axis (xdit_context_parallel.py:142): ONE ``all_gather_into_tensor`` into a
+    rank-major buffer; for a single batch row that buffer IS the result (a view), otherwise one transposing copy puts
+    the batch axis back in front (the model output is [B, N/P, 128]: a few MB)."""
     world = dist.get_world_size(group)
-    parts = [torch.empty_like(x) for _ in range(world)]
-    dist.all_gather(parts, x.contiguous(), group=group)
-    return torch.cat(parts, dim=dim)
+    if dim != 1:
+        x = x.transpose(1, dim)
+    x = x.contiguous()
+    buf = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(buf.view(-1), x.view(-1), group=group)          # (flat: the form every backend takes)
+    if x.shape[0] == 1:
+        out = buf.view((1, world * x.shape[1]) + tuple(x.shape[2:]))
+    else:
+        out = buf.transpose(0, 1).reshape((x.shape[0], world * x.shape[1]) + tuple(x.shape[2:]))
+    return out if dim == 1 else out.transpose(1, dim)
 
 
 def seq_to_head_shard(qkv, group=None):
@@ -146,14 +156,13 @@ class UlyssesAttnProcessor:
             orecv = osend
         host_mask = _host_mask(skip_layer_mask) if skip_layer_mask is not None else None
         if host_mask is not None and any(m != 1.0 for m in host_mask):
-            # STG blends (attention.py:1127-1141) on the K-blocked layout, one head group at a time
+            # STG blends (attention.py:1127-1141) on the K-blocked layout [P][B, Nl][Dp] in ONE launch: channel block p of
+            # token (b, n) of the blended-in tensor lies p * Dp further along its row
             m_dev = skip_layer_mask.reshape(B).to(torch.float32)
-            for p in range(P):
-                a3 = orecv[p].view(B, Nl, Dp)
-                if skip_layer_strategy == SkipLayerStrategy.AttentionValues:
-                    ops.stg_blend_(a3, qkv.view(B, Nl, 3 * D)[:, :, 2 * D + p * Dp: 2 * D + (p + 1) * Dp], m_dev)
-                elif skip_layer_strategy == SkipLayerStrategy.AttentionSkip:
-                    ops.stg_blend_(a3, hidden_states[:, :, p * Dp:(p + 1) * Dp], m_dev)
+            if skip_layer_strategy == SkipLayerStrategy.AttentionValues:
+                ops.stg_blend_grouped_(orecv.view(P, B, Nl, Dp), qkv.view(B, Nl, 3 * D)[:, :, 2 * D:], m_dev)
+            elif skip_layer_strategy == SkipLayerStrategy.AttentionSkip:
+                ops.stg_blend_grouped_(orecv.view(P, B, Nl, Dp), hidden_states, m_dev)
         w_o, b_o = attn.to_out[0].weight, attn.to_out[0].bias
         a_blk0 = orecv[0].view(B * Nl, Dp)
         kb = dict(a_kblock=Dp, a_kblock_stride=B * Nl * Dp) if P > 1 else {}
@@ -166,13 +175,70 @@ class UlyssesAttnProcessor:
         return ops.gemm(a_blk0, w_o, b_o, **kb).view(B, Nl, -1)
 
 
-def enable_sequence_parallel(model, group=None):
-    """Install the Ulysses processor on every block's self-attention."""
+def enable_sequence_parallel(model, group=None, overlap=True):
+    """Install the Ulysses processor on every block's self-attention.
+
+    ``overlap`` (default on; takes effect at world size > 1 with >= 2 batch rows): the block loop runs the batch as TWO
+    micro-batches, each on a stream of its own (``Transformer3DModel.forward(_microbatches=...)``).  Inside a block
+    everything depends on the step before it, so an exchange can only be hidden behind work of ANOTHER batch row: while
+    one micro-batch waits for its all-to-all (RCCL runs it on the process group's communication stream), the other
+    one's projection / attention / to_out / FF kernels run.  Rows are computed independently of each other by every
+    kernel, so the result is the same as without the split (tests: world size 2, torch.equal)."""
     for blk in model.transformer_blocks:
         assert isinstance(blk, BasicTransformerBlock)
         blk.attn1.set_processor(UlyssesAttnProcessor(group))
     model._sp_group = group
+    model._sp_overlap = bool(overlap)
+    model._sp_interrupt = _InterruptAgreement()
     return model
+
+
+def microbatch_slices(B):
+    """The two micro-batches of the overlap mode: rows [0, B/2) and [B/2, B) (B_eff = 3: the uncond row | text + STG rows)."""
+    h = max(B // 2, 1)
+    return [slice(0, h), slice(h, B)]
+
+
+class _InterruptAgreement:
+    """The reference's cooperative cancel (``ltxv_model._interrupt`` polled before every block, transformer3d.py:468-469)
+    is a per-process flag: under sequence parallelism one rank leaving the block loop while the others wait in an
+    all-to-all would hang the group, so the ranks must AGREE on it (MAX all-reduce).  Reading the agreed value on the
+    host in the same forward would drain the launch queue once per denoise step (the host runs about a step ahead of the
+    device); instead forward k posts its flag -- all-reduce, then an asynchronous copy into pinned host memory behind an
+    event -- and forward k + 1 reads it: no host synchronisation on a step's critical path, every rank sees the same
+    value in the same forward, and a cancel takes effect one forward (one denoise step) after it was raised."""
+
+    def __init__(self):
+        self.pending = None
+        self.consts = {}
+
+    def poll_and_post(self, local_flag, device, group):
+        agreed = False
+        if self.pending is not None:
+            host, ev = self.pending
+            if ev is not None:
+                ev.synchronize()                 # recorded a whole forward ago: long complete
+            agreed = bool(int(host[0]))
+        if agreed:
+            self.pending = None                  # consumed: the next forward starts afresh
+            return True
+        if device.type == "cuda":
+            c = self.consts.get(device)
+            if c is None:
+                c = self.consts[device] = (torch.zeros(1, dtype=torch.int32, device=device),
+                                           torch.ones(1, dtype=torch.int32, device=device),
+                                           torch.zeros(1, dtype=torch.int32).pin_memory())
+            flag = c[1 if local_flag else 0].clone()
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            c[2].copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending = (c[2], ev)
+        else:
+            flag = torch.tensor([1 if local_flag else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            self.pending = (flag, None)
+        return False
 
 
 def usp_dit_forward(model, hidden_states, freqs_cis, encoder_hidden_states=None, timestep=None,
@@ -191,17 +257,16 @@ def usp_dit_forward(model, hidden_states, freqs_cis, encoder_hidden_states=None,
             raise ValueError("per-token timesteps need whole latent frames per rank")
         timestep = shard_tokens(timestep, rank, world)
         latent_shape = (latent_shape[0] // world,) + tuple(latent_shape[1:])
-    # The reference's cooperative cancel (``ltxv_model._interrupt`` polled before every block, transformer3d.py:468-469)
-    # is a per-process flag: under sequence parallelism one rank leaving the block loop while the others wait in an
-    # all-to-all would hang the group.  The flag is therefore agreed on ONCE per forward, here (MAX all-reduce), and the
-    # blocks run with a frozen copy of the agreed value.
+    # cooperative cancel: agreed between the ranks without a host synchronisation (see _InterruptAgreement); the blocks
+    # run with a frozen copy of the agreed value
     holder = kw.pop("ltxv_model", None)
     if holder is not None:
-        flag = torch.tensor([1 if getattr(holder, "_interrupt", False) else 0], dtype=torch.int32, device=hidden_states.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-        if int(flag.item()):
+        agree = model.__dict__.setdefault("_sp_interrupt", _InterruptAgreement())
+        if agree.poll_and_post(bool(getattr(holder, "_interrupt", False)), hidden_states.device, group):
             return [None]
         kw["ltxv_model"] = _Frozen()
+    if getattr(model, "_sp_overlap", False) and world > 1 and hidden_states.shape[0] >= 2:
+        kw["_microbatches"] = microbatch_slices(hidden_states.shape[0])
     out = model(hs, freqs_cis=fc, encoder_hidden_states=encoder_hidden_states, timestep=timestep,
                 encoder_attention_mask=encoder_attention_mask, skip_layer_mask=skip_layer_mask,
                 skip_layer_strategy=skip_layer_strategy, latent_shape=latent_shape, return_dict=False, **kw)
@@ -214,29 +279,53 @@ class _Frozen:
 
 
 # ------------------------------------------------------------------ VAE decode: z-tiles over the ranks
-def tile_parallel_vae_decode(latents, vae, is_video=True, vae_per_channel_normalize=False, timestep=None, group=None):
-    """``vae_decode`` with the z-tiles of the tiled decode (vae.py:365-402) spread over the ranks: tile n is decoded by
-    rank n mod P and broadcast (shape first, then the fp16 pixels); the cross-fades and the concatenation then run on
-    every rank, so every rank returns the full video -- the same bits as the single-rank tiled decode.  No collective
-    inside a convolution.  Falls back to the plain decode when z-tiling is off or the clip is a single tile."""
-    from .autoencoder import vae_decode
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    dev = latents.device
+def exchange_tiles(decoders, shapes, group=None, dtype=torch.float16, device=None, trace=None):
+    """Two phases.  (1) This rank decodes ALL the tiles it owns (tile n belongs to rank n mod P), each straight into its
+    slot of one flat send buffer -- no collective is issued before the last local decode has been enqueued, so the
+    ranks' decodes run concurrently.  (2) ONE ``all_gather_into_tensor`` of the (padded) send buffers; every tile is then
+    a contiguous view of the receive buffer.  The tile shapes are computed by the caller from the latent slices, so
+    nothing about them has to be communicated and no host synchronisation happens anywhere.
 
-    def owner(n, decode_tile):
-        src = n % world
-        src_global = dist.get_global_rank(group, src) if group is not None else src
-        if src == rank:
-            tile = decode_tile()
-            shape = torch.tensor(list(tile.shape), device=dev, dtype=torch.int64)
-        else:
-            tile = None
-            shape = torch.zeros(5, device=dev, dtype=torch.int64)
-        dist.broadcast(shape, src=src_global, group=group)
-        if tile is None:
-            tile = torch.empty([int(v) for v in shape.tolist()], device=dev, dtype=torch.float16)
-        dist.broadcast(tile, src=src_global, group=group)
-        return tile
+    ``decoders[n](out)`` decodes tile n into ``out`` (a contiguous tensor of shape ``shapes[n]``); ``trace`` (tests)
+    receives ("decode", n) / ("collective", name) in issue order."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    T = len(decoders)
+    numel = [int(math.prod(s)) for s in shapes]
+    per_rank = [sum(numel[n] for n in range(r, T, world)) for r in range(world)]
+    cap = max(max(per_rank), 1)
+    cap = -(-cap // 8) * 8                                    # 16-byte granules
+    recv = torch.empty((world, cap), dtype=dtype, device=device)
+    send = recv[rank] if world == 1 else torch.empty(cap, dtype=dtype, device=device)
+    off = 0
+    for n in range(rank, T, world):                            # phase 1: local decodes only
+        if trace is not None:
+            trace.append(("decode", n))
+        decoders[n](send[off:off + numel[n]].view(shapes[n]))
+        off += numel[n]
+    if world > 1:                                              # phase 2: the one exchange
+        if trace is not None:
+            trace.append(("collective", "all_gather_into_tensor"))
+        dist.all_gather_into_tensor(recv.view(-1), send, group=group)
+    tiles, offs = [], [0] * world
+    for n in range(T):
+        r = n % world
+        tiles.append(recv[r, offs[r]:offs[r] + numel[n]].view(shapes[n]))
+        offs[r] += numel[n]
+    return tiles
+
+
+def tile_parallel_vae_decode(latents, vae, is_video=True, vae_per_channel_normalize=False, timestep=None, group=None,
+                             _trace=None):
+    """``vae_decode`` with the z-tiles of the tiled decode (vae.py:365-402) spread over the ranks (tiles are
+    independent until the overlap blends): rank r decodes tiles r, r + P, ... back to back, ONE all-gather exchanges the
+    fp16 pixels (``exchange_tiles``), then the cross-fades and the concatenation run on every rank, so every rank returns
+    the full video -- the same bits as the single-rank tiled decode.  No collective inside a convolution, none before the
+    last local decode.  Falls back to the plain decode when z-tiling is off or the clip is a single tile."""
+    from .autoencoder import vae_decode
+    world = dist.get_world_size(group)
+
+    def exchange(decoders, shapes):
+        return exchange_tiles(decoders, shapes, group=group, dtype=torch.float16, device=latents.device, trace=_trace)
 
     return vae_decode(latents, vae, is_video, vae_per_channel_normalize=vae_per_channel_normalize, timestep=timestep,
-                      _tile_owner=owner if world > 1 else None)
+                      _tile_exchange=exchange if world > 1 else None)

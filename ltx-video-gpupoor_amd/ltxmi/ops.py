@@ -76,6 +76,17 @@ def _rows(t):
     return t2, t2.shape[0], t2.stride(0)
 
 
+def tensor_version(t):
+    """``t._version`` for the cache keys of packed weights and derived caches.  Inference tensors (weights created,
+    loaded or cast under ``torch.inference_mode()``) track no version counter and raise on the read: the key then rests
+    on storage, dtype and device alone (-1 here).  Edits made through ``.data`` bump no counter either: after those
+    call ``invalidate_packed()`` on the module (``Attention`` / ``CausalConv3d``)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, gate_table=None, gate_temb=None,
          rows_per_group=1, algo=0, rowsumsq=None, rowsumsq_cols=0, a_kblock=0, a_kblock_stride=0):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  ``a``/``out``/``residual`` may be row-strided 2-D views.
@@ -184,9 +195,17 @@ def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None,
         if out_segments is not None:
             raise ValueError("ltxmi.attention: out_segments needs an explicit out")
         out = torch.empty((B, Lq, H, dh), dtype=BF16, device=q.device)
+    if out.dim() != 4 or out.stride(3) != 1 or out.stride(2) != dh:
+        raise ValueError("ltxmi.attention: out must be 4-D with (heads, head_dim) contiguous")
     a = _lib.AttnArgs()
     if out_segments is not None:
-        a.o_segment_len, a.o_stride_segment = out_segments
+        seg_len, seg_stride = out_segments
+        if seg_len <= 0 or Lq % seg_len != 0 or tuple(out.shape) != (B, seg_len, H, dh):
+            raise ValueError(f"ltxmi.attention: out_segments=({seg_len}, {seg_stride}) needs Lq={Lq} to be a multiple of the "
+                             f"segment and out to be segment 0's [B, segment, H, dh] view, got {tuple(out.shape)}")
+        a.o_segment_len, a.o_stride_segment = seg_len, seg_stride
+    elif tuple(out.shape) != (B, Lq, H, dh):
+        raise ValueError(f"ltxmi.attention: out must be [B, Lq, H, dh] = {(B, Lq, H, dh)}, got {tuple(out.shape)}")
     a.q, a.q_stride_b, a.q_stride_l = q.data_ptr(), q.stride(0), q.stride(1)
     a.k, a.k_stride_b, a.k_stride_l = k.data_ptr(), k.stride(0), k.stride(1)
     a.v, a.v_stride_b, a.v_stride_l = v.data_ptr(), v.stride(0), v.stride(1)
@@ -237,6 +256,18 @@ def qkv_norm_rope_pack(qkv, B, Nl, D, P, q_weight, k_weight, eps, cos=None, sin=
                                             _ptr(sin), ld_tab, rope_period, _ptr(out), _stream()),
           "ltxmi_qkv_norm_rope_pack_bf16")
     return out
+
+
+def stg_blend_grouped_(a, v, m_f32):
+    """a [G, B, L, Dg] contiguous (the K-blocked layout: channel block g of every row), v [B, L, >= G*Dg] with channels
+    contiguous: a[g] = a[g] * m + v[..., g*Dg:(g+1)*Dg] * (1 - m), one launch."""
+    _chk_bf16(a, v)
+    G, B, L, Dg = a.shape
+    if not a.is_contiguous() or v.dim() != 3 or v.shape[0] != B or v.shape[1] != L or v.shape[2] < G * Dg or v.stride(2) != 1:
+        raise ValueError("ltxmi.stg_blend_grouped_: a must be contiguous [G,B,L,Dg], v [B,L,>=G*Dg] with unit channel stride")
+    check(lib.ltxmi_stg_blend_grouped_bf16(_ptr(a), _ptr(v), Dg, v.stride(0), v.stride(1), _ptr(m_f32), G, B, L, Dg, _stream()),
+          "ltxmi_stg_blend_grouped_bf16")
+    return a
 
 
 def silu(x, out=None):

@@ -9,6 +9,7 @@ convention (:328-345, :504-507), ``precompute_freqs_cis`` (:202-255) and
 Weights live fully in HBM (3.85 GB bf16 for the 2B config): the reference's mmgp block
 offloading has no counterpart here.
 """
+import contextlib
 import math
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional
@@ -189,6 +190,47 @@ class Transformer3DModel(nn.Module):
             sin_freq = torch.cat([torch.zeros_like(cos_freq[:, :, : dim % 6]), sin_freq], dim=-1)
         return cos_freq.to(self.dtype).contiguous(), sin_freq.to(self.dtype).contiguous()
 
+    def _run_blocks_microbatched(self, hidden_states, slices, freqs_cis, attention_mask, encoder_hidden_states,
+                                 encoder_attention_mask, temb, cross_attention_kwargs, class_labels, layer_mask,
+                                 skip_layer_strategy, ltxv_model):
+        """The block loop over micro-batches of batch rows, micro-batch i on side stream i (plain sequential on the CPU).
+        The host issues block b of every micro-batch before block b + 1 of any, so the collectives of the slices
+        interleave in one fixed order on every rank.  The blocks update ``hidden_states`` in place through the row views.
+        Returns True when interrupted."""
+        B = hidden_states.shape[0]
+        on_gpu = hidden_states.is_cuda
+        streams = None
+        if on_gpu:
+            main = torch.cuda.current_stream()
+            key = (hidden_states.device, len(slices))
+            pool = self.__dict__.setdefault("_mb_streams", {})
+            streams = pool.get(key)
+            if streams is None:
+                streams = pool[key] = [torch.cuda.Stream(device=hidden_states.device) for _ in slices]
+            for st in streams:
+                st.wait_stream(main)
+
+        def rows(t, sl):
+            return t if (t is None or t.shape[0] != B) else t[sl]
+
+        interrupted = False
+        for block_idx, block in enumerate(self.transformer_blocks):
+            for i, sl in enumerate(slices):
+                ctx = torch.cuda.stream(streams[i]) if on_gpu else contextlib.nullcontext()
+                with ctx:
+                    block(hidden_states[sl], freqs_cis=tuple(rows(t, sl) for t in freqs_cis), attention_mask=attention_mask,
+                          encoder_hidden_states=rows(encoder_hidden_states, sl),
+                          encoder_attention_mask=rows(encoder_attention_mask, sl), timestep=temb[sl],
+                          cross_attention_kwargs=cross_attention_kwargs, class_labels=class_labels,
+                          skip_layer_mask=layer_mask(block_idx, sl), skip_layer_strategy=skip_layer_strategy)
+            if ltxv_model is not None and ltxv_model._interrupt:
+                interrupted = True
+                break
+        if on_gpu:
+            for st in streams:
+                main.wait_stream(st)
+        return interrupted
+
     # ------------------------------------------------------------------ forward
     def forward(self, hidden_states: torch.Tensor, freqs_cis: list,
                 encoder_hidden_states: Optional[torch.Tensor] = None, timestep: Optional[torch.Tensor] = None,
@@ -196,14 +238,18 @@ class Transformer3DModel(nn.Module):
                 attention_mask: Optional[torch.Tensor] = None, encoder_attention_mask: Optional[torch.Tensor] = None,
                 skip_layer_mask: Optional[torch.Tensor] = None,
                 skip_layer_strategy: Optional[SkipLayerStrategy] = None, latent_shape=None, joint_pass=True,
-                ltxv_model=None, mixed=False, return_dict: bool = True, stg_alias_blocks: int = 0):
+                ltxv_model=None, mixed=False, return_dict: bool = True, stg_alias_blocks: int = 0,
+                _microbatches=None):
         """``stg_alias_blocks`` (extension, default off): the caller guarantees that the LAST batch row has
         exactly the inputs of the row before it (the STG "perturbed" row is the text row until its first
         skipped block, pipeline_ltx_video.py:1035-1051) -- the first ``stg_alias_blocks`` blocks then run on
         B - 1 rows and the last row is filled in by a copy.  Bit-identical to running all rows: every kernel
         computes a row independently of the others, the GEMM kernels all accumulate over K in the same order and share
         their epilogue arithmetic (so the tile choice made from M does not matter), and the request is ignored when
-        B - 1 and B rows would be served by different self-attention kernels (``ops.attention_kernel_id``)."""
+        B - 1 and B rows would be served by different self-attention kernels (``ops.attention_kernel_id``).
+        ``_microbatches`` (extension, set by ltxmi.distributed): a list of batch-row slices; the block loop then runs
+        every block once per slice, each slice on a stream of its own, so that one slice's collectives (sequence
+        parallelism) are hidden behind the other slices' kernels.  Rows are independent: same result."""
         if self.dtype != BF16:
             raise TypeError("ltxmi.Transformer3DModel runs in bfloat16 only: call .to(torch.bfloat16)")
         if mixed:
@@ -239,8 +285,8 @@ class Transformer3DModel(nn.Module):
             # (prompt tensor, weights) and hand the SAME tensor to the blocks, whose text K/V caches key on it
             ehs = encoder_hidden_states
             cp = self.caption_projection
-            key = (ehs.data_ptr(), tuple(ehs.shape), ehs.dtype, ehs._version, cp.linear_1.weight.data_ptr(),
-                   cp.linear_1.weight._version, cp.linear_2.weight.data_ptr(), cp.linear_2.weight._version)
+            key = (ehs.data_ptr(), tuple(ehs.shape), ehs.dtype, ops.tensor_version(ehs), cp.linear_1.weight.data_ptr(),
+                   ops.tensor_version(cp.linear_1.weight), cp.linear_2.weight.data_ptr(), ops.tensor_version(cp.linear_2.weight))
             cache = self.__dict__.setdefault("_caption_cache", {})
             hit = cache.get(key) if ops.STEP_INVARIANT_CACHING else None
             if hit is None:
@@ -284,7 +330,12 @@ class Transformer3DModel(nn.Module):
                 if ltxv_model is not None and ltxv_model._interrupt:
                     return [None]
             hidden_states[B - 1].copy_(hidden_states[B - 2])
-        if joint_pass:
+        if joint_pass and _microbatches and len(_microbatches) > 1 and first_block == 0:
+            if self._run_blocks_microbatched(hidden_states, _microbatches, freqs_cis, attention_mask, encoder_hidden_states,
+                                             encoder_attention_mask, temb, cross_attention_kwargs, class_labels,
+                                             layer_mask, skip_layer_strategy, ltxv_model):
+                return [None]
+        elif joint_pass:
             for block_idx, block in enumerate(self.transformer_blocks):
                 if block_idx < first_block:
                     continue

@@ -160,8 +160,16 @@ def stg_blend_(a, v, m_f32):
     return a
 
 
+def stg_blend_grouped_(a, v, m_f32):
+    G, B, L, Dg = a.shape
+    m = m_f32.float().view(1, B, 1, 1)
+    vv = v[:, :, :G * Dg].float().reshape(B, L, G, Dg).permute(2, 0, 1, 3)
+    a.copy_((a.float() * m + vv * (1 - m)).to(a.dtype))
+    return a
+
+
 NAMES = ["gemm", "norm_modulate", "rmsnorm_rope_", "attention_fuses_qnorm", "attention_kernel_id", "attention", "qkv_norm_rope_pack", "silu",
-         "timestep_embedding", "stg_blend_"]
+         "timestep_embedding", "stg_blend_", "stg_blend_grouped_"]
 
 
 def install():

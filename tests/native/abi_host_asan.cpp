@@ -62,7 +62,11 @@ int main() {
     expect_fail(ltxmi_gemm_bf16(&g, nullptr), "gemm(rowsumsq, no device)");
     g.rowsumsq_cols = 2000;
     expect_fail(ltxmi_gemm_bf16(&g, nullptr), "gemm(rowsumsq_cols % 64)");
-    g.rowsumsq = nullptr; g.rowsumsq_cols = 0;
+    // a caller that leaves the tail fields of an older struct unset: NULL pointer, garbage cols / ld -- must be
+    // treated as "off" (the launcher zeroes them), never as a store descriptor based at address 0
+    g.rowsumsq = nullptr; g.rowsumsq_cols = 0x7fffff00; g.rowsumsq_ld = -12345;
+    expect_fail(ltxmi_gemm_bf16(&g, nullptr), "gemm(NULL rowsumsq, garbage cols/ld, no device)", LTXMI_ERR_LAUNCH);
+    g.rowsumsq = nullptr; g.rowsumsq_cols = 0; g.rowsumsq_ld = 0;
     g.a_kblock = 1024; g.a_kblock_stride = 4992 * 1024; g.lda = 1024;
     expect_fail(ltxmi_gemm_bf16(&g, nullptr), "gemm(K-blocked A, no device)");
     g.a_kblock = 1000;
@@ -177,6 +181,9 @@ int main() {
     expect_fail(ltxmi_ndhwc_to_ncdhw_bf16(nullptr, 256, 0, p, 1, 128, 2, 8, 8, pf, pf, nullptr), "ndhwc_to_ncdhw(NULL)");
     expect_fail(ltxmi_stg_blend_bf16(nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr), "stg_blend(NULL)");
     expect_fail(ltxmi_stg_blend_bf16(p, 2048, p, 6144, pf, 3, 4992, 2048, nullptr), "stg_blend(no device)");
+    expect_fail(ltxmi_stg_blend_grouped_bf16(nullptr, nullptr, 0, 0, 0, nullptr, 0, 0, 0, 0, nullptr), "stg_blend_grouped(NULL)");
+    expect_fail(ltxmi_stg_blend_grouped_bf16(p, p, 256, 624 * 6144, 6144, pf, 8, 3, 624, 250, nullptr), "stg_blend_grouped(D % 8)");
+    expect_fail(ltxmi_stg_blend_grouped_bf16(p, p, 256, 624 * 6144, 6144, pf, 8, 3, 624, 256, nullptr), "stg_blend_grouped(no device)");
     expect_fail(ltxmi_guidance_step_bf16(p, 4992 * 128, 3, 3.f, 1.f, 0.7f, 1, 1, 1, pf, 0, -0.1f, pf, nullptr), "guidance_step(no device)");
     expect_fail(ltxmi_guidance_step_bf16(p, 4992 * 128, 4, 3.f, 1.f, 0.7f, 1, 1, 1, pf, 0, -0.1f, pf, nullptr), "guidance_step(num_conds 4)");
     expect_fail(ltxmi_guidance_step_bf16(p, 4992 * 128, 3, 3.f, 1.f, 0.7f, 1, 1, 1, pf, 0, -0.1f, nullptr, nullptr), "guidance_step(no workspace)");

@@ -137,9 +137,15 @@ def _usp_case(rank, world, per_token):
     ltxmi, m, x, fc, kw = _dit_setup(per_token)
     with torch.no_grad():
         ref = m(x.clone(), freqs_cis=fc, return_dict=False, **kw)[0]                 # one rank, default processor
-        sp.enable_sequence_parallel(m)
-        out = sp.usp_dit_forward(m, x.clone(), fc, **kw)[0]                          # tokens sharded over the ranks
+        sp.enable_sequence_parallel(m, overlap=False)
+        plain = sp.usp_dit_forward(m, x.clone(), fc, **kw)[0]                        # tokens sharded over the ranks
+        sp.enable_sequence_parallel(m)                                               # default: two micro-batches of rows
+        assert m._sp_overlap
+        out = sp.usp_dit_forward(m, x.clone(), fc, **kw)[0]
     assert out.shape == ref.shape
+    # the micro-batched block loop (what hides the exchanges behind the other rows' kernels) computes every row as the
+    # plain loop does
+    assert torch.equal(out, plain)
     err = float((out.float() - ref.float()).norm() / ref.float().norm())
     # every op is row-wise: the two runs differ only by matmul blocking (row counts differ) before a bf16 rounding
     assert err < 2e-3, err
@@ -156,8 +162,9 @@ def _case_usp_dit_forward_per_token(rank, world):
 
 
 def _case_usp_interrupt_is_collective(rank, world):
-    """ltxv_model._interrupt raised on ONE rank: every rank returns [None] (agreed once per forward), nobody is left
-    waiting in an all-to-all."""
+    """ltxv_model._interrupt raised on ONE rank: the ranks agree on it without a host synchronisation in the step (the
+    flag posted by forward k is read by forward k + 1), so the forward in which it was raised still completes on EVERY
+    rank and the next one returns [None] on EVERY rank -- nobody is left waiting in an all-to-all."""
     from ltxmi import distributed as sp
     ltxmi, m, x, fc, kw = _dit_setup(False)
     sp.enable_sequence_parallel(m)
@@ -165,13 +172,43 @@ def _case_usp_interrupt_is_collective(rank, world):
     class Holder:
         _interrupt = (rank == 1)
 
-    with torch.no_grad():
-        assert sp.usp_dit_forward(m, x.clone(), fc, ltxv_model=Holder(), **kw) == [None]
+    class Quiet:
+        _interrupt = False
 
-        class Quiet:
-            _interrupt = False
+    with torch.no_grad():
         out = sp.usp_dit_forward(m, x.clone(), fc, ltxv_model=Quiet(), **kw)
-    assert out[0] is not None and out[0].shape == (3, 24, 128)
+        assert out[0] is not None and out[0].shape == (3, 24, 128)
+        first = sp.usp_dit_forward(m, x.clone(), fc, ltxv_model=Holder(), **kw)       # raised on rank 1 only: posted
+        assert first[0] is not None and torch.equal(first[0], out[0])
+        assert sp.usp_dit_forward(m, x.clone(), fc, ltxv_model=Quiet(), **kw) == [None]   # agreed: every rank leaves
+        again = sp.usp_dit_forward(m, x.clone(), fc, ltxv_model=Quiet(), **kw)        # consumed: back to normal
+    assert again[0] is not None and torch.equal(again[0], out[0])
+
+
+def _case_exchange_tiles(rank, world):
+    """The two-phase tile exchange of tile_parallel_vae_decode: every rank decodes ALL its tiles (n = rank mod P) before
+    the one collective; uneven tile counts and sizes; the tiles come back as they were written."""
+    from ltxmi import distributed as sp
+    shapes = [(1, 3, 33, 4, 6)] + [(1, 3, 32, 4, 6)] * 3 + [(1, 3, 9, 4, 6)]        # 5 tiles: rank 0 owns 3, rank 1 owns 2
+    want = [torch.randn(s, generator=torch.Generator().manual_seed(100 + n)).to(torch.float16) for n, s in enumerate(shapes)]
+    decoded = []
+
+    def make(n):
+        def dec(out):
+            assert tuple(out.shape) == shapes[n] and out.is_contiguous() and out.dtype == torch.float16
+            decoded.append(n)
+            out.copy_(want[n])
+        return dec
+
+    trace = []
+    tiles = sp.exchange_tiles([make(n) for n in range(5)], shapes, dtype=torch.float16, trace=trace)
+    assert decoded == list(range(rank, 5, world))                                     # only its own tiles
+    assert len(tiles) == 5 and all(torch.equal(t, w) and t.is_contiguous() for t, w in zip(tiles, want))
+    kinds = [k for k, _ in trace]
+    assert kinds.count("collective") == 1 and kinds.index("collective") == len(decoded) == len(kinds) - 1, trace
+    # in-place edits of one tile (the blends) must not touch its neighbours in the receive buffer
+    tiles[1].zero_()
+    assert torch.equal(tiles[0], want[0]) and torch.equal(tiles[2], want[2]) and torch.equal(tiles[3], want[3])
 
 
 def test_ulysses_layout_world2():
@@ -196,3 +233,11 @@ def test_usp_dit_forward_per_token_timesteps_world2():
 
 def test_usp_interrupt_is_collective_world2():
     _run("_case_usp_interrupt_is_collective")
+
+
+def test_exchange_tiles_two_phase_world2():
+    _run("_case_exchange_tiles")
+
+
+def test_exchange_tiles_world3():
+    _run("_case_exchange_tiles", world=3)

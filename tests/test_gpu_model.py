@@ -1011,15 +1011,15 @@ def _tile_parallel_decode_worker(rank, world, port, q):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        bcast = dist.broadcast
+        gather = dist.all_gather_into_tensor
 
-        def broadcast(t, src=0, group=None, **kw):                 # gloo moves host tensors: staged in the test worker
-            if not t.is_cuda:
-                return bcast(t, src=src, group=group, **kw)
-            h = t.cpu()
-            bcast(h, src=src, group=group, **kw)
-            t.copy_(h)
-        dist.broadcast = broadcast
+        def all_gather_into_tensor(out, x, group=None, **kw):      # gloo moves host tensors: staged in the test worker
+            if not x.is_cuda:
+                return gather(out, x, group=group, **kw)
+            h = torch.empty(out.shape, dtype=out.dtype)
+            gather(h, x.cpu(), group=group, **kw)
+            out.copy_(h)
+        dist.all_gather_into_tensor = all_gather_into_tensor
         import ltxmi
         from ltxmi import distributed as sp
         cfg, sd = vae_case("b", base=64)
@@ -1029,10 +1029,14 @@ def _tile_parallel_decode_worker(rank, world, port, q):
         ts = torch.tensor([0.05], device=DEV)
         with torch.no_grad():
             ref = ltxmi.vae_decode(z, v, True, vae_per_channel_normalize=True, timestep=ts)         # every tile on this rank
-            out = sp.tile_parallel_vae_decode(z, v, True, vae_per_channel_normalize=True, timestep=ts)
+            trace = []
+            out = sp.tile_parallel_vae_decode(z, v, True, vae_per_channel_normalize=True, timestep=ts, _trace=trace)
         torch.cuda.synchronize()
         assert out.shape == ref.shape == (1, 3, 73, 64, 96) and out.dtype == torch.float16
         assert torch.equal(out, ref)
+        # concurrency, structurally: this rank's tiles (n = rank mod 2) are ALL decoded before the one collective is
+        # issued -- no collective sits between two local decodes, so the ranks' decodes overlap in time
+        assert trace == [("decode", n) for n in range(rank, 4, world)] + [("collective", "all_gather_into_tensor")], trace
         q.put((rank, "ok"))
         dist.barrier()
         dist.destroy_process_group()
@@ -1041,9 +1045,9 @@ def _tile_parallel_decode_worker(rank, world, port, q):
 
 
 def test_tile_parallel_vae_decode_world2_on_one_gpu():
-    """SURVEY 8e, VAE row: the z-tiles of a tiled decode spread over the ranks (tile n on rank n mod P, broadcast, blends on
-    every rank) -- world size 2, both ranks on the box's one GPU, gloo transport -- gives the single-rank tiled decode bit
-    for bit on every rank."""
+    """SURVEY 8e, VAE row: the z-tiles of a tiled decode spread over the ranks (rank r decodes tiles r, r + P, ... back to
+    back, ONE all-gather, blends on every rank) -- world size 2, both ranks on the box's one GPU, gloo transport -- gives
+    the single-rank tiled decode bit for bit on every rank, with no collective issued before the last local decode."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:

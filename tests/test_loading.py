@@ -110,3 +110,23 @@ def test_packed_weights_follow_in_place_edits():
         conv.conv.weight.mul_(0.5)
     p2, _ = conv.packed()
     assert p2 is not p1 and torch.allclose(p2.float(), p1.float() * 0.5, atol=1e-2)
+    # what the key can NOT see: an edit through .data bumps no version counter -> the pack is stale until
+    # invalidate_packed() (documented on Attention._pack / CausalConv3d.packed)
+    v0 = att.to_q.weight._version
+    att.to_q.weight.data.add_(1.0)
+    assert att.to_q.weight._version == v0
+    stale, _ = att.packed_qkv()
+    assert not torch.equal(stale[:128], att.to_q.weight)
+    att.invalidate_packed()
+    assert torch.equal(att.packed_qkv()[0][:128], att.to_q.weight)
+    conv.conv.weight.data.mul_(2.0)
+    conv.invalidate_packed()
+    assert torch.allclose(conv.packed()[0].float(), p1.float(), atol=1e-2)
+    # inference tensors track no version counter at all: the key must not raise on them (storage-only key)
+    with torch.inference_mode():
+        att_i = Attention(query_dim=128, heads=2, dim_head=64, bias=True, qk_norm="rms_norm")
+        conv_i = CausalConv3d(64, 64)
+    assert att_i.to_q.weight.is_inference()
+    wi, _ = att_i.packed_qkv()
+    assert wi.shape == (384, 128) and att_i.packed_qkv()[0] is wi
+    assert conv_i.packed()[0].shape == (64, 27 * 64)
