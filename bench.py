@@ -391,7 +391,17 @@ def _stage_collectives_through_host(dist):
         bcast(h, src=src, group=group, **kw)
         t.copy_(h)
 
+    gather_flat = dist.all_gather_into_tensor
+
+    def all_gather_into_tensor(out, x, group=None, **kw):
+        if not x.is_cuda:
+            return gather_flat(out, x, group=group, **kw)
+        h = torch.empty(out.shape, dtype=out.dtype)
+        gather_flat(h, x.cpu(), group=group, **kw)
+        out.copy_(h)
+
     dist.all_to_all_single, dist.all_gather, dist.all_reduce, dist.broadcast = all_to_all_single, all_gather, all_reduce, broadcast
+    dist.all_gather_into_tensor = all_gather_into_tensor
 
 
 def launch_ranks(n, argv):

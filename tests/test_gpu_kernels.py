@@ -658,13 +658,21 @@ def test_attention_full_size_properties_98k():
     v3 = (0.5 * v1.float() + 0.25 * v2.float()).to(BF)
     o3 = ops.attention(q, k, v3).float()
     lin = 0.5 * o1 + 0.25 * o2
-    assert (o3 - lin).norm() / lin.norm() < 2e-2                 # at N = 98k the outputs are ~1/sqrt(N) small
+    # Tolerances (round 3: the file's own, derived -- the 2e-2 / 6e-2 of round 2 were not).  The kernel's error against
+    # fp32 is one bf16 rounding of P (independent per key: relative 2^-9 / sqrt(3) rms on a random-sign sum, whatever N)
+    # plus one bf16 rounding of the output (the same again): ~1.6e-3 rms relative, i.e. REL_L2 = 3e-3 holds at ANY
+    # sequence length.  Linearity compares three such renderings (+ the bf16 rounding of v3 itself), the permutation two
+    # independent ones: sqrt(4) x 1.1e-3 and sqrt(2) x 1.6e-3 -> 4e-3 bounds both.
+    e_lin = float((o3 - lin).norm() / lin.norm())
     perm = torch.randperm(N, generator=g, device=DEV)
     op = ops.attention(q, k[:, perm], v1[:, perm]).float()
-    assert (op - o1).norm() / o1.norm() < 2e-2
+    e_perm = float((op - o1).norm() / o1.norm())
+    print(f"98k attention: linearity {e_lin:.3e}, key permutation {e_perm:.3e}")
+    assert e_lin < 4e-3 and e_perm < 4e-3, (e_lin, e_perm)
     rows = slice(50000, 50064)
     truth = attn_truth(q[:, rows].cpu(), k.cpu(), v1.cpu())
-    check(o1[:, rows], truth, rel_l2=2e-2, maxrel=6e-2, what="98k attention, 64 query rows vs oracle")
+    e = check(o1[:, rows], truth, what="98k attention, 64 query rows vs oracle")
+    print(f"98k attention: 64 query rows vs the fp32 oracle: rel L2 {e:.3e}")
 
 
 def test_gemm_full_size_linearity_ff1_shape():
@@ -809,10 +817,12 @@ def test_attention_config_shapes_properties(B, H, N, dh):
     o1, o2 = ops.attention(q, k, v1).float(), ops.attention(q, k, v2).float()
     o3 = ops.attention(q, k, (0.5 * v1.float() + 0.25 * v2.float()).to(BF)).float()
     lin = 0.5 * o1 + 0.25 * o2
-    assert (o3 - lin).norm() / lin.norm() < 2e-2
+    e_lin = float((o3 - lin).norm() / lin.norm())
+    assert e_lin < 4e-3, e_lin                                       # (derivation: test_attention_full_size_properties_98k)
     for rows in (slice(0, 64), slice(N - 70, N)):                    # first tile and the ragged end
         truth = attn_truth(q[:, rows].cpu(), k.cpu(), v1.cpu())
-        check(o1[:, rows], truth, rel_l2=2e-2, maxrel=6e-2, what=f"attention N{N} dh{dh} rows {rows}")
+        e = check(o1[:, rows], truth, what=f"attention N{N} dh{dh} rows {rows}")   # the file's REL_L2 / MAXREL
+        print(f"attention N{N} dh{dh} rows {rows}: rel L2 {e:.3e}, linearity {e_lin:.3e}")
     # cross-attention of config 4: 512 text keys, no bias
     kc, vc = k[:, :512].contiguous(), v1[:, :512].contiguous()
     oc = ops.attention(q, kc, vc)
@@ -1003,3 +1013,42 @@ def test_tile_blend(dtype, dim, extent):
     untouched = [slice(None)] * 5
     untouched[dim] = slice(e, None)
     assert torch.equal(out.cpu()[tuple(untouched)], b[tuple(untouched)])
+
+
+def test_gemm_ignores_rowsumsq_fields_without_a_pointer():
+    """a C caller that leaves rowsumsq_cols / rowsumsq_ld unset (garbage) next to a NULL rowsumsq pointer must
+    get the plain GEMM -- the plain epilogue runs on the row-sums kernel instance, whose extra stores used to take their
+    geometry from those fields."""
+    import ctypes
+    from ltxmi import _lib, ops
+    M, N, K = 2048, 512, 256                                 # persistent 256x256 kernel (M >= 1024, >= 128 tiles? no: small) ...
+    for (M, N, K) in ((2048, 512, 256), (8192, 4096, 128)):  # the 128x128 tile kernel and the persistent 256x256 one
+        a, w = rnd(M, K, seed=41).to(DEV), rnd(N, K, seed=42, scale=K ** -0.5).to(DEV)
+        guard = torch.full((M * N + 4096,), 7.0, dtype=BF, device=DEV)
+        out = guard[:M * N].view(M, N)
+        args = _lib.GemmArgs()
+        args.A, args.lda, args.W, args.ldw = a.data_ptr(), K, w.data_ptr(), K
+        args.C, args.ldc, args.M, args.N, args.K = out.data_ptr(), N, M, N, K
+        args.rows_per_group = 1
+        args.rowsumsq, args.rowsumsq_cols, args.rowsumsq_ld = None, 0x7fffff00, -12345
+        _lib.check(_lib.lib.ltxmi_gemm_bf16(ctypes.byref(args), ops._stream()), "ltxmi_gemm_bf16")
+        torch.cuda.synchronize()
+        check(out, a.float().cpu() @ w.float().cpu().T, what=f"gemm {M}x{N}x{K} with garbage rowsumsq fields")
+        assert (guard[M * N:] == 7.0).all()
+
+
+def test_stg_blend_grouped_matches_per_group_blends():
+    """The one-launch STG blend over the K-blocked layout [P][B, Nl][D/P] of the Ulysses return exchange against P
+    launches of the plain blend (attention.py:1127-1141 arithmetic)."""
+    from ltxmi import ops
+    P, B, Nl, Dp = 4, 3, 37, 128
+    D = P * Dp
+    a = rnd(P, B, Nl, Dp, seed=51).to(DEV)
+    qkv = rnd(B, Nl, 3 * D, seed=52).to(DEV)
+    m = torch.tensor([1.0, 1.0, 0.0], device=DEV)
+    want = a.clone()
+    for p in range(P):
+        ops.stg_blend_(want[p], qkv[:, :, 2 * D + p * Dp: 2 * D + (p + 1) * Dp], m)
+    got = ops.stg_blend_grouped_(a.clone(), qkv[:, :, 2 * D:], m)
+    assert torch.equal(got, want)
+    assert torch.equal(got[:, :2], a[:, :2]) and not torch.equal(got[:, 2], a[:, 2])

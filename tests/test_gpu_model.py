@@ -368,30 +368,125 @@ def test_vae_decode_full_width():
     assert_parity(out, truth, eager, "vae decode, base 128")
 
 
-def test_vae_decode_bench_size_both_convolutions_agree():
-    """Config 2's decode (z [1,128,13,16,24] -> 97 x 512 x 768, base 128) is far beyond the CPU oracle.  The decoder is
-    run twice on the GPU -- convolutions chosen by shape (the direct kernel wherever it applies: what the bench times)
-    and all of them as implicit GEMMs -- two independent implementations, each oracle-checked at these widths on
-    crops / small latents (test_gpu_kernels.py), that must agree on the full-size result."""
+def _vae_small_eager_error(cfg, sd):
+    """What the reference's bf16 eager decode loses against fp32 with THESE weights, measured where the CPU can run the
+    bf16 oracle (the latent of test_vae_decode_full_width): (rel L2, max err / range).  The full-size tests below bound
+    the product's error by it (+ BASELINE's 2e-3) -- the per-element error of a decode does not depend on how many
+    positions there are."""
+    from oracle import vae as ov
+    z = torch.randn(1, 128, 3, 6, 8, generator=torch.Generator().manual_seed(17)).to(BF)
+    ts = torch.tensor([0.05])
+    truth = ov.vae_decode(sd, cfg, z.float(), ts)
+    sdb = {k: (v.to(BF) if v.is_floating_point() and v.dim() > 0 else v) for k, v in sd.items()}
+    eager = ov.vae_decode(sdb, cfg, z, ts)
+    return rel(eager, truth), maxrel(eager, truth)
+
+
+def _assert_full_size_parity(out, truth, e_ref, m_ref, what):
+    e, m = rel(out, truth), maxrel(out, truth)
+    print(f"{what}: rel L2 {e:.3e} (bound: bf16 eager {e_ref:.3e} + {RTOL});  max err / range {m:.3e} (eager {m_ref:.3e})")
+    assert torch.isfinite(out.float()).all(), what
+    assert e <= e_ref + RTOL, (what, e, e_ref)
+    assert m <= 1.5 * m_ref + 1e-2, (what, m, m_ref)
+    return e
+
+
+def _cpu_threads():
+    import os
+    n = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(n)
+    return n
+
+
+def test_vae_decode_config2_full_size_vs_fp32_oracle():
+    """BASELINE config 2's decode at FULL size -- z [1,128,13,16,24] -> 97 x 512 x 768, decoder_base_channels 128, the
+    tensors the bench times -- against the fp32 CPU oracle (24.4 TFLOP on the host: about a minute on 16 threads), for
+    BOTH convolution paths: chosen by shape (the direct kernel wherever it applies) and all-implicit-GEMM.  Round 2 only
+    compared the two with each other."""
+    import time
+    from oracle import vae as ov
     import ltxmi
     from ltxmi import ops
     cfg, sd = vae_case("b", base=128)
+    e_ref, m_ref = _vae_small_eager_error(cfg, sd)
     v = build_vae(cfg, sd)
-    z = torch.randn(1, 128, 13, 16, 24, generator=torch.Generator().manual_seed(18)).to(BF).to(DEV)
-    ts = torch.tensor([0.05], device=DEV)
-    out = ltxmi.vae_decode(z, v, True, vae_per_channel_normalize=True, timestep=ts)
-    assert out.shape == (1, 3, 97, 512, 768) and torch.isfinite(out.float()).all()
+    z = torch.randn(1, 128, 13, 16, 24, generator=torch.Generator().manual_seed(18)).to(BF)
+    ts = torch.tensor([0.05])
+    out = ltxmi.vae_decode(z.to(DEV), v, True, vae_per_channel_normalize=True, timestep=ts.to(DEV))
+    assert out.shape == (1, 3, 97, 512, 768)
     old = ops.CONV_ALGO
     try:
         ops.CONV_ALGO = 1
-        ref = ltxmi.vae_decode(z, v, True, vae_per_channel_normalize=True, timestep=ts)
+        out_ig = ltxmi.vae_decode(z.to(DEV), v, True, vae_per_channel_normalize=True, timestep=ts.to(DEV))
     finally:
         ops.CONV_ALGO = old
-    e = rel(out, ref)
-    print(f"bench-size decode, direct vs implicit-GEMM convolutions: rel L2 {e:.3e}")
-    # each path is a bf16 rendering ~8e-3 from the fp32 truth (test_vae_decode_full_width); two INDEPENDENT renderings
-    # differ by up to sqrt(2) times that.  An indexing / padding / chunking error shows up at 1e-1 .. 1.
-    assert e < 1.5e-2 and maxrel(out, ref) < 8e-2
+    out, out_ig = out.cpu(), out_ig.cpu()
+    n = _cpu_threads()
+    t0 = time.time()
+    with torch.no_grad():
+        truth = ov.vae_decode(sd, cfg, z.float(), ts)
+    print(f"fp32 oracle decode of config 2 on {n} host threads: {time.time() - t0:.1f} s")
+    assert truth.shape == out.shape
+    e_d = _assert_full_size_parity(out, truth, e_ref, m_ref, "config-2 decode, convolutions by shape")
+    e_i = _assert_full_size_parity(out_ig, truth, e_ref, m_ref, "config-2 decode, all implicit GEMM")
+    # the two renderings against each other: bounded by the triangle inequality from the two oracle distances (round 2's
+    # 8e-3 was a guess that the measured 9.7e-3 broke: two independent renderings ~8e-3 from the truth sit ~sqrt(2) x
+    # that apart).  Kept as a report + the exact bound.
+    e_x = rel(out, out_ig)
+    print(f"config-2 decode, direct vs implicit GEMM: rel L2 {e_x:.3e} (oracle distances {e_d:.3e} / {e_i:.3e})")
+    assert e_x <= (e_d + e_i) * 1.05 + 1e-4
+
+
+def test_vae_decode_config5_full_size_tiled():
+    """BASELINE config 5 at FULL size: z [1,128,33,23,40] -> 257 frames of 736 x 1280, z-tiled by 4 latent frames (11
+    tiles, vae.py:365-402).  (a) tile 0 alone (5 latent frames, 22 TFLOP) against the fp32 CPU oracle; (b) the tiled
+    output's frames before the first blend are tile 0's untiled decode bit for bit; (c) every later tile's unblended
+    middle frames equal that tile's own untiled decode; (d) the whole tiled output with all-implicit-GEMM convolutions
+    against the one with convolutions chosen by shape."""
+    import time
+    from oracle import vae as ov
+    import ltxmi
+    from ltxmi import ops
+    cfg, sd = vae_case("b", base=128)
+    e_ref, m_ref = _vae_small_eager_error(cfg, sd)
+    v = build_vae(cfg, sd)
+    z = torch.randn(1, 128, 33, 23, 40, generator=torch.Generator().manual_seed(19)).to(BF)
+    ts = torch.tensor([0.05])
+    zd, tsd = z.to(DEV), ts.to(DEV)
+    v.enable_z_tiling(4)
+    tiled = ltxmi.vae_decode(zd, v, True, vae_per_channel_normalize=True, timestep=tsd)
+    assert tiled.shape == (1, 3, 257, 736, 1280) and tiled.dtype == torch.float16 and torch.isfinite(tiled.float()).all()
+    old = ops.CONV_ALGO
+    try:
+        ops.CONV_ALGO = 1
+        tiled_ig = ltxmi.vae_decode(zd, v, True, vae_per_channel_normalize=True, timestep=tsd)
+    finally:
+        ops.CONV_ALGO = old
+    v.disable_z_tiling()
+    # (b) frames 0 .. 24 of the tiled output = tile 0 (latent frames 0 .. 4) decoded on its own, in fp16
+    tile0 = ltxmi.vae_decode(zd[:, :, 0:5], v, True, vae_per_channel_normalize=True, timestep=tsd)
+    assert tile0.shape == (1, 3, 33, 736, 1280)
+    assert torch.equal(tiled[:, :, :25], tile0.to(torch.float16)[:, :, :25])
+    # (c) tile n (latent frames 3n .. 3n + 4) contributes output frames 25 + 24 (n - 1) ... ; its first 8 are cross-faded
+    # with tile n - 1, the next 16 are its own frames 9 .. 24 (frame 0 dropped) untouched
+    for n in (1, 5, 10):
+        zt = zd[:, :, 3 * n:3 * n + 5]
+        own = ltxmi.vae_decode(zt, v, True, vae_per_channel_normalize=True, timestep=tsd).to(torch.float16)[:, :, 1:]
+        lo = 25 + 24 * (n - 1)
+        keep = min(24, own.shape[2]) - 8
+        assert torch.equal(tiled[:, :, lo + 8:lo + 8 + keep], own[:, :, 8:8 + keep]), f"tile {n}"
+    # (d) the two convolution paths over the whole tiled clip (bound: twice the oracle distance allowed per path)
+    e_x = rel(tiled, tiled_ig)
+    print(f"config-5 tiled decode, direct vs implicit GEMM: rel L2 {e_x:.3e}")
+    assert e_x <= 2 * (e_ref + RTOL)
+    del tiled_ig
+    # (a) tile 0 against the fp32 oracle
+    n = _cpu_threads()
+    t0 = time.time()
+    with torch.no_grad():
+        truth = ov.vae_decode(sd, cfg, z[:, :, 0:5].float(), ts)
+    print(f"fp32 oracle decode of config 5's tile 0 on {n} host threads: {time.time() - t0:.1f} s")
+    _assert_full_size_parity(tile0.cpu(), truth, e_ref, m_ref, "config-5 tile 0 (5 x 23 x 40 latents)")
 
 
 def test_vae_decoder_block_variants():
@@ -932,7 +1027,17 @@ def _host_staged_collectives():
         reduce(h, op=op, group=group, **kw)
         t.copy_(h)
 
+    gather_flat = dist.all_gather_into_tensor
+
+    def all_gather_into_tensor(out, x, group=None, **kw):
+        if not x.is_cuda:
+            return gather_flat(out, x, group=group, **kw)
+        h = torch.empty(out.shape, dtype=out.dtype)
+        gather_flat(h, x.cpu(), group=group, **kw)
+        out.copy_(h)
+
     dist.all_to_all_single, dist.all_gather, dist.all_reduce = all_to_all_single, all_gather, all_reduce
+    dist.all_gather_into_tensor = all_gather_into_tensor
 
 
 def _ulysses_world2_worker(rank, world, port, per_token, q):
@@ -951,8 +1056,16 @@ def _ulysses_world2_worker(rank, world, port, per_token, q):
         _host_staged_collectives()
         import ltxmi
         from ltxmi import distributed as sp
-        grid, B, T = (4, 16, 16), 3, 32                           # N = 1024 tokens, 512 per rank, 2 frames per rank
-        cfg, sd32, x, enc, mask, ts, frac = dit_case(4, 64, 2, grid, B, T, seed=31, per_token=per_token)
+        if per_token == "p8shape":
+            # what ONE rank sees at P = 8 on the 2B model, reproduced at P = 2: 8 heads of 64 -> H/P = 4 local heads,
+            # D/P = 256-wide exchange blocks, 3 x 4 x 16 = 192 workgroups of 256 query rows -> the pipelined attention
+            # kernel writing the segmented output
+            grid, B, T, heads, per_token = (4, 32, 32), 3, 32, 8, False
+            from ltxmi import ops
+            assert ops.attention_kernel_id(B, heads // world, 4096, 4096, 64) == ops.attention_kernel_id(3, 32, 4992, 4992, 64)
+        else:
+            grid, B, T, heads = (4, 16, 16), 3, 32, 4                 # N = 1024 tokens, 512 per rank, 2 frames per rank
+        cfg, sd32, x, enc, mask, ts, frac = dit_case(heads, 64, 2, grid, B, T, seed=31, per_token=per_token)
         m = build_model(cfg, sd32)
         fc = m.precompute_freqs_cis(frac.to(DEV))
         kw = dict(encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV), timestep=ts.to(DEV),
@@ -960,11 +1073,17 @@ def _ulysses_world2_worker(rank, world, port, per_token, q):
                   skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=grid)
         with torch.no_grad():
             ref = m(x.to(DEV).clone(), freqs_cis=fc, return_dict=False, **kw)[0]      # one rank, default processor
-            sp.enable_sequence_parallel(m)
-            out = sp.usp_dit_forward(m, x.to(DEV).clone(), fc, **kw)[0]               # tokens sharded over 2 ranks
+            sp.enable_sequence_parallel(m, overlap=False)
+            plain = sp.usp_dit_forward(m, x.to(DEV).clone(), fc, **kw)[0]             # tokens sharded over 2 ranks
+            sp.enable_sequence_parallel(m)                                            # + rows as two micro-batches on two streams
+            out = sp.usp_dit_forward(m, x.to(DEV).clone(), fc, **kw)[0]
         torch.cuda.synchronize()
         err = float((out.float() - ref.float()).norm() / ref.float().norm())
         assert out.shape == ref.shape and torch.isfinite(out.float()).all()
+        # the overlap mode (micro-batches of rows on side streams) changes no bit when both modes take the same attention
+        # kernel; at the small shape the row split moves attention below the pipelined kernel's threshold: close instead
+        e_mb = float((out.float() - plain.float()).norm() / plain.float().norm())
+        assert e_mb < 2e-3, e_mb
         # same kernels on the same rows; only the GEMM tile positions and the heads-per-launch of attention differ
         assert err < 2e-3, err
         q.put((rank, "ok", err))
@@ -974,7 +1093,7 @@ def _ulysses_world2_worker(rank, world, port, per_token, q):
         q.put((rank, traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("per_token", [False, True])
+@pytest.mark.parametrize("per_token", [False, True, "p8shape"])
 def test_ulysses_world2_real_kernels_on_one_gpu(per_token):
     """usp_dit_forward + UlyssesAttnProcessor at WORLD SIZE 2 with the real kernels: two processes share the box's one
     GPU, the all-to-alls travel over gloo (host-staged in the workers).  Everything device-side is what runs on a
