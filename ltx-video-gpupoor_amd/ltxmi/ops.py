@@ -29,7 +29,8 @@ _events = {}
 
 
 def watch_launches(keys):
-    """keys: iterable of ("gemm", M, N, K, epilogue) / ("attention", B, H, Lq, Lk, dh) tuples, or None."""
+    """keys: iterable of ("gemm", M, N, K, epilogue) / ("attention", B, H, Lq, Lk, dh) /
+    ("conv3d", output positions, Cin, Cout, d2s) tuples, or None."""
     global _watch
     _watch = set(keys) if keys else None
     _events.clear()
@@ -356,7 +357,9 @@ def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, a
         if not add.is_contiguous() or add.shape != (B, oT, oH, oW, Cout):
             raise ValueError("ltxmi.conv3d: `add` must be a contiguous [B,T,H,W,Cout] tensor")
         a.add = add.data_ptr()
+    tok = _prof_begin(("conv3d", B * oT * oH * oW, Cin, Cout, int(d2s)))
     check(lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), _stream()), "ltxmi_conv3d_ndhwc_bf16")
+    _prof_end(tok)
     return out
 
 
