@@ -124,6 +124,14 @@ int ltxmi_rmsnorm_rope_bf16(void* x, int64_t ldx, int32_t rows, int32_t D,
                             const void* weight, float eps,
                             const void* cos_tab, const void* sin_tab, int64_t ld_tab,
                             int32_t rope_period, void* stream);
+/* The same pass (k of self-attention) and, riding on the launch, the RMSNorm factor of ANOTHER tensor's rows (q):
+ * rstd_out[r] = rsqrt(sum_j rowsumsq[r * rowsumsq_ld + j] / norm_dim + norm_eps), j < rowsumsq_blocks -- the per-64-column
+ * sums of squares ltxmi_gemm_bf16 wrote for the q columns of the fused QKV projection (attention.py:1040-1041: q_norm is an
+ * RMSNorm over all heads).  ltxmi_attention_fwd_bf16 takes the result as q_rstd. */
+int ltxmi_rmsnorm_rope_rstd_bf16(void* x, int64_t ldx, int32_t rows, int32_t D, const void* weight, float eps,
+                                 const void* cos_tab, const void* sin_tab, int64_t ld_tab, int32_t rope_period,
+                                 const float* rowsumsq, int64_t rowsumsq_ld, int32_t rowsumsq_blocks,
+                                 int32_t norm_dim, float norm_eps, float* rstd_out, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Flash attention forward (non-causal, softmax scale given), bf16 in/out, fp32 softmax.
@@ -157,6 +165,11 @@ typedef struct ltxmi_attn_args {
      * (token l of batch b at o[(l / o_segment_len) * o_stride_segment + b * o_stride_b + (l % o_segment_len) * o_stride_l]):
      * the send buffer of the Ulysses return all-to-all, [P destination ranks][B][N / P][H dh], written in place.  0 = off. */
     int32_t o_segment_len; int64_t o_stride_segment;
+    /* 0.3 -- q's RMSNorm factor already finalised: q_rstd[b * stride_b + l * stride_l] = rsqrt(mean(x^2) + eps) of the raw
+     * projection row (written by ltxmi_rmsnorm_rope_rstd_bf16 from the GEMM's partial sums, riding on k's pass).  Given,
+     * it replaces q_rowsumsq (every workgroup -- one per head and query tile -- then reads 4 bytes per row instead of
+     * re-summing H*head_dim/64 partials); q_norm_weight / rope_* as above.  NULL = off. */
+    const float* q_rstd; int64_t q_rstd_stride_b, q_rstd_stride_l;
 } ltxmi_attn_args;
 
 int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* args, void* stream);

@@ -16,11 +16,32 @@ struct AttnParams {
     // optional: q arrives as the raw projection output; RMSNorm over all H * dh channels (row sums of squares
     // given as per-64-column partials by the projection GEMM) x weight, then interleaved RoPE, applied on load
     const float* q_ss; int64_t q_ss_sb, q_ss_sl; int q_ss_n;
+    // ... or, finalised (one float per row: rsqrt(mean(x^2) + eps), ltxmi_rmsnorm_rope_rstd_bf16); takes precedence
+    const float* q_rstd; int64_t q_rstd_sb, q_rstd_sl;
     const uint16_t* q_w; float q_eps;
     const uint16_t* rope_cos; const uint16_t* rope_sin; int64_t rope_sb, rope_sl;
     // optional: the output's token axis is cut into segments of o_seg tokens, o_sseg elements apart (Ulysses: the
     // return all-to-all's send buffer [P dst][B][N / P][H dh]); 0 = one segment
     int o_seg; int64_t o_sseg;
+
+    __device__ __forceinline__ bool q_on_load() const { return q_ss != nullptr || q_rstd != nullptr; }
+    // q's RMSNorm factor of row `row` of batch b (HD = H * head_dim, the normalised width)
+    __device__ __forceinline__ float q_row_rstd(int b, int row, int HD) const {
+        if (q_rstd) return q_rstd[(int64_t)b * q_rstd_sb + (int64_t)row * q_rstd_sl];
+        const float* ss = q_ss + (int64_t)b * q_ss_sb + (int64_t)row * q_ss_sl;
+        float s2 = 0.f;
+        if ((q_ss_n & 3) == 0 && (((uintptr_t)ss) & 15) == 0) {
+            // (one 16-byte load per four partials: the row's partials are contiguous)
+            const f32x4* ss4 = (const f32x4*)ss;
+            for (int j = 0; j < (q_ss_n >> 2); ++j) {
+                const f32x4 v4 = ss4[j];
+                s2 += (v4[0] + v4[1]) + (v4[2] + v4[3]);
+            }
+        } else {
+            for (int j = 0; j < q_ss_n; ++j) s2 += ss[j];
+        }
+        return rsqrtf(s2 / (float)HD + q_eps);
+    }
 
     __device__ __forceinline__ int64_t o_row(int row) const {
         if (o_seg <= 0) return (int64_t)row * o_sl;

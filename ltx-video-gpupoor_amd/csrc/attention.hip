@@ -99,26 +99,11 @@ __global__ __launch_bounds__(256, (QB == 2 || DH == 128) ? 2 : 1) void attn_fwd_
         // optional: q is the raw projection output; q_norm (RMSNorm over all H * dh channels from the projection GEMM's
         // partial sums of squares, x weight) and the interleaved-pair RoPE are applied here, with the arithmetic of
         // rmsnorm_rope_kernel (rowops.hip): fp32, one rounding to bf16 at the end (see attention_pipe.hip)
-        float rstd = 0.f;
-        if (p.q_ss) {
-            const float* ss = p.q_ss + (int64_t)b * p.q_ss_sb + (int64_t)q_ld * p.q_ss_sl;
-            float s2 = 0.f;
-            if ((p.q_ss_n & 3) == 0 && (((uintptr_t)ss) & 15) == 0) {
-                // (one 16-byte load per four partials: the row's partials are contiguous)
-                const f32x4* ss4 = (const f32x4*)ss;
-                for (int j = 0; j < (p.q_ss_n >> 2); ++j) {
-                    const f32x4 v4 = ss4[j];
-                    s2 += (v4[0] + v4[1]) + (v4[2] + v4[3]);
-                }
-            } else {
-                for (int j = 0; j < p.q_ss_n; ++j) s2 += ss[j];
-            }
-            rstd = rsqrtf(s2 / (float)(p.H * DH) + p.q_eps);
-        }
+        const float rstd = p.q_on_load() ? p.q_row_rstd(b, q_ld, p.H * DH) : 0.f;
 #pragma unroll
         for (int s = 0; s < C::KSTEPS; ++s) {
             qf[i][s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * hh);
-            if (p.q_ss) {
+            if (p.q_on_load()) {
                 const int col = head * DH + 16 * s + 8 * hh;
                 const bf16x8 wv = *(const bf16x8*)(p.q_w + col);
                 float o[8];
@@ -493,6 +478,7 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     p.q_tiles = (a->Lq + Q_PER_WG - 1) / Q_PER_WG;
     p.q_ss = a->q_rowsumsq; p.q_ss_sb = a->q_rowsumsq_stride_b; p.q_ss_sl = a->q_rowsumsq_stride_l;
     p.q_ss_n = a->q_rowsumsq_blocks;
+    p.q_rstd = a->q_rstd; p.q_rstd_sb = a->q_rstd_stride_b; p.q_rstd_sl = a->q_rstd_stride_l;
     p.q_w = (const uint16_t*)a->q_norm_weight; p.q_eps = a->q_norm_eps;
     p.rope_cos = (const uint16_t*)a->rope_cos; p.rope_sin = (const uint16_t*)a->rope_sin;
     p.rope_sb = a->rope_stride_b; p.rope_sl = a->rope_stride_l;
@@ -500,10 +486,11 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     LTXMI_REQUIRE(a->o_segment_len >= 0 && a->o_stride_segment % 8 == 0, LTXMI_ERR_INVALID_ARG,
                   "ltxmi_attention_fwd_bf16: bad output segment geometry");
     const bool pipe_ok = attn_pipe_takes(a->B, a->H, a->Lq, a->Lk, a->head_dim, a->key_bias != nullptr);
-    if (a->q_rowsumsq) {
-        LTXMI_REQUIRE(a->q_norm_weight && a->q_rowsumsq_blocks == a->H * a->head_dim / 64 &&
-                          (((uintptr_t)a->q_rowsumsq) & 3) == 0 && (((uintptr_t)a->q_norm_weight) & 15) == 0,
-                      LTXMI_ERR_INVALID_ARG, "ltxmi_attention_fwd_bf16: bad q_rowsumsq / q_norm_weight geometry");
+    if (a->q_rowsumsq || a->q_rstd) {
+        LTXMI_REQUIRE(a->q_norm_weight && (((uintptr_t)a->q_norm_weight) & 15) == 0 &&
+                          (a->q_rstd ? (((uintptr_t)a->q_rstd) & 3) == 0
+                                     : (a->q_rowsumsq_blocks == a->H * a->head_dim / 64 && (((uintptr_t)a->q_rowsumsq) & 3) == 0)),
+                      LTXMI_ERR_INVALID_ARG, "ltxmi_attention_fwd_bf16: bad q_rowsumsq / q_rstd / q_norm_weight geometry");
         LTXMI_REQUIRE((a->rope_cos == nullptr) == (a->rope_sin == nullptr), LTXMI_ERR_INVALID_ARG,
                       "ltxmi_attention_fwd_bf16: rope_cos and rope_sin must both be given or both be NULL");
         if (a->rope_cos)

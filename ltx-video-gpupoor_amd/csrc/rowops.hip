@@ -88,10 +88,21 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(uint16_t* __restrict_
                                                            const uint16_t* __restrict__ w, float eps,
                                                            const uint16_t* __restrict__ cs,
                                                            const uint16_t* __restrict__ sn, int64_t ld_tab,
-                                                           int rope_period) {
+                                                           int rope_period, const float* __restrict__ side_ss,
+                                                           int64_t side_ld, int side_n, float side_inv_d, float side_eps,
+                                                           float* __restrict__ side_rstd) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (side_ss) {
+        // riding on this launch (k's pass of self-attention): the RMSNorm factor of the SAME row of q from the projection
+        // GEMM's per-64-column sums of squares -- one float per row, so that the attention kernel's workgroups (one per
+        // head and query tile) read 4 bytes per row instead of re-summing the row's partials each
+        float t = 0.f;
+        for (int j = lane; j < side_n; j += 64) t += side_ss[(int64_t)row * side_ld + j];
+        t = wave_sum(t);
+        if (lane == 0) side_rstd[row] = rsqrtf(t * side_inv_d + side_eps);
+    }
     const int nchunk = D >> 3;
     uint16_t* xr = x + (int64_t)row * ldx;
     Chunk c[NCH];
@@ -372,9 +383,35 @@ extern "C" int ltxmi_norm_modulate_bf16(const void* x, int64_t ldx, void* y, int
     return check_launch("ltxmi_norm_modulate_bf16");
 }
 
+static int rmsnorm_rope_launch(void* x, int64_t ldx, int32_t rows, int32_t D, const void* weight, float eps,
+                               const void* cos_tab, const void* sin_tab, int64_t ld_tab, int32_t rope_period,
+                               const float* side_ss, int64_t side_ld, int32_t side_n, int32_t side_d, float side_eps,
+                               float* side_rstd, void* stream);
+
 extern "C" int ltxmi_rmsnorm_rope_bf16(void* x, int64_t ldx, int32_t rows, int32_t D, const void* weight, float eps,
                                        const void* cos_tab, const void* sin_tab, int64_t ld_tab,
                                        int32_t rope_period, void* stream) {
+    return rmsnorm_rope_launch(x, ldx, rows, D, weight, eps, cos_tab, sin_tab, ld_tab, rope_period, nullptr, 0, 0, 1, 0.f,
+                               nullptr, stream);
+}
+
+extern "C" int ltxmi_rmsnorm_rope_rstd_bf16(void* x, int64_t ldx, int32_t rows, int32_t D, const void* weight, float eps,
+                                            const void* cos_tab, const void* sin_tab, int64_t ld_tab, int32_t rope_period,
+                                            const float* rowsumsq, int64_t rowsumsq_ld, int32_t rowsumsq_blocks,
+                                            int32_t norm_dim, float norm_eps, float* rstd_out, void* stream) {
+    LTXMI_REQUIRE(rowsumsq && rstd_out, LTXMI_ERR_INVALID_ARG, "ltxmi_rmsnorm_rope_rstd_bf16: NULL rowsumsq / rstd_out");
+    LTXMI_REQUIRE(rowsumsq_blocks > 0 && norm_dim > 0 && rowsumsq_ld >= rowsumsq_blocks &&
+                      ((((uintptr_t)rowsumsq) | ((uintptr_t)rstd_out)) & 3) == 0,
+                  LTXMI_ERR_INVALID_ARG, "ltxmi_rmsnorm_rope_rstd_bf16: bad rowsumsq geometry (blocks %d, ld %lld, dim %d)",
+                  rowsumsq_blocks, (long long)rowsumsq_ld, norm_dim);
+    return rmsnorm_rope_launch(x, ldx, rows, D, weight, eps, cos_tab, sin_tab, ld_tab, rope_period, rowsumsq, rowsumsq_ld,
+                               rowsumsq_blocks, norm_dim, norm_eps, rstd_out, stream);
+}
+
+static int rmsnorm_rope_launch(void* x, int64_t ldx, int32_t rows, int32_t D, const void* weight, float eps,
+                               const void* cos_tab, const void* sin_tab, int64_t ld_tab, int32_t rope_period,
+                               const float* side_ss, int64_t side_ld, int32_t side_n, int32_t side_d, float side_eps,
+                               float* side_rstd, void* stream) {
     LTXMI_REQUIRE(x && weight, LTXMI_ERR_INVALID_ARG, "ltxmi_rmsnorm_rope_bf16: NULL argument");
     LTXMI_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr), LTXMI_ERR_INVALID_ARG,
                   "ltxmi_rmsnorm_rope_bf16: cos and sin must both be given or both be NULL");
@@ -387,7 +424,8 @@ extern "C" int ltxmi_rmsnorm_rope_bf16(void* x, int64_t ldx, int32_t rows, int32
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_rope_kernel<NCH>), dim3(grid), dim3(256), 0, s, (uint16_t*)x, ldx,
                                        rows, D, (const uint16_t*)weight, eps, (const uint16_t*)cos_tab,
-                                       (const uint16_t*)sin_tab, ld_tab, rope_period > 0 ? rope_period : 1))
+                                       (const uint16_t*)sin_tab, ld_tab, rope_period > 0 ? rope_period : 1, side_ss, side_ld,
+                                       side_n, 1.0f / (float)side_d, side_eps, side_rstd))
     return check_launch("ltxmi_rmsnorm_rope_bf16");
 }
 

@@ -33,7 +33,8 @@ class AttnArgs(ctypes.Structure):
                 ("q_rowsumsq", c_void_p), ("q_rowsumsq_stride_b", c_int64), ("q_rowsumsq_stride_l", c_int64),
                 ("q_rowsumsq_blocks", c_int), ("q_norm_weight", c_void_p), ("q_norm_eps", c_float),
                 ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("rope_stride_b", c_int64), ("rope_stride_l", c_int64),
-                ("o_segment_len", c_int), ("o_stride_segment", c_int64)]
+                ("o_segment_len", c_int), ("o_stride_segment", c_int64),
+                ("q_rstd", c_void_p), ("q_rstd_stride_b", c_int64), ("q_rstd_stride_l", c_int64)]
 
 
 class Conv3dArgs(ctypes.Structure):
@@ -55,6 +56,8 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ltxmi_rmsnorm_rope_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p,
                                         c_int64, c_int, c_void_p]),
+    "ltxmi_rmsnorm_rope_rstd_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p,
+                                             c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p]),
     "ltxmi_qkv_norm_rope_pack_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                               c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "ltxmi_attention_fwd_bf16": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),

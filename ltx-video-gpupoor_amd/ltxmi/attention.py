@@ -254,10 +254,15 @@ class AttnProcessor2_0:
                 period = cos2.shape[0]                  # N (shared) or B*N (per sample)
                 cos, sin = cos2, sin2
             if fuse_q:
-                q_fused = ((ss, attn.q_norm.weight, attn.q_norm.eps), (cos, sin, period) if cos is not None else None)
+                # k's pass also finalises q's row factor (one float per row) from the GEMM's partial sums: the attention
+                # kernel's (head, query tile) workgroups then read 4 bytes per row instead of re-summing 32 partials each
+                rstd = torch.empty((B * N,), dtype=torch.float32, device=x2.device)
+                ops.rmsnorm_rope_(k2, attn.k_norm.weight, attn.k_norm.eps, cos, sin, period,
+                                  rstd_of=(ss, D, attn.q_norm.eps, rstd))
+                q_fused = ((rstd, attn.q_norm.weight, attn.q_norm.eps), (cos, sin, period) if cos is not None else None)
             else:
                 ops.rmsnorm_rope_(q2, attn.q_norm.weight, attn.q_norm.eps, cos, sin, period)
-            ops.rmsnorm_rope_(k2, attn.k_norm.weight, attn.k_norm.eps, cos, sin, period)
+                ops.rmsnorm_rope_(k2, attn.k_norm.weight, attn.k_norm.eps, cos, sin, period)
             Lk = N
             q4 = qkv.view(B, N, 3, H, dh)[:, :, 0]
             k4 = qkv.view(B, N, 3, H, dh)[:, :, 1]

@@ -151,9 +151,11 @@ def norm_modulate(x, out, eps, kind, scale_table, scale_temb, shift_table, shift
     return out
 
 
-def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, rope_period=0):
+def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, rope_period=0, rstd_of=None):
     """In place: x = rope(rmsnorm(x) * weight).  x: 2-D row-strided view [rows, D];
-    cos/sin: [period, D] tables (row r uses row r % period) or None."""
+    cos/sin: [period, D] tables (row r uses row r % period) or None.
+    rstd_of = (rowsumsq fp32 [rows, blocks], norm_dim, eps, out fp32 [rows]): riding on the launch, out[r] =
+    rsqrt(sum(rowsumsq[r]) / norm_dim + eps) -- q's RMSNorm factor from the projection GEMM's partial sums."""
     _chk_bf16(x, weight, cos, sin)
     x2, rows, ldx = _rows(x)
     D = x2.shape[1]
@@ -163,6 +165,15 @@ def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, rope_period=0):
             raise ValueError("ltxmi.rmsnorm_rope_: cos/sin must be matching 2-D tables")
         ld_tab = cos.stride(0)
         rope_period = rope_period or cos.shape[0]
+    if rstd_of is not None:
+        ss, norm_dim, norm_eps, out = rstd_of
+        if ss.dtype != torch.float32 or out.dtype != torch.float32 or ss.dim() != 2 or ss.shape[0] != rows or \
+                ss.stride(1) != 1 or out.shape != (rows,) or not out.is_contiguous():
+            raise ValueError("ltxmi.rmsnorm_rope_: rstd_of needs fp32 sums [rows, blocks] and a contiguous fp32 out [rows]")
+        check(lib.ltxmi_rmsnorm_rope_rstd_bf16(_ptr(x2), ldx, rows, D, _ptr(weight), eps, _ptr(cos), _ptr(sin), ld_tab,
+                                               rope_period, _ptr(ss), ss.stride(0), ss.shape[1], norm_dim, norm_eps,
+                                               _ptr(out), _stream()), "ltxmi_rmsnorm_rope_rstd_bf16")
+        return x
     check(lib.ltxmi_rmsnorm_rope_bf16(_ptr(x2), ldx, rows, D, _ptr(weight), eps, _ptr(cos), _ptr(sin), ld_tab,
                                       rope_period, _stream()), "ltxmi_rmsnorm_rope_bf16")
     return x
@@ -181,9 +192,9 @@ def attention_kernel_id(B, H, Lq, Lk, dh, has_key_bias=False):
 def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None, rope=None, out_segments=None):
     """q [B,Lq,H,dh], k/v [B,Lk,H,dh] (NHD; batch and token strides free, (H,dh) contiguous).
     key_bias: fp32 [B,Lk] additive (broadcast over heads and queries).
-    q_norm = (rowsumsq fp32 [B*Lq, H*dh/64] from ``gemm(..., rowsumsq=)``, weight bf16 [H*dh], eps): q is the raw
-    projection output and is RMS-normalised over all heads (+ rotated with rope = (cos [period, H*dh], sin, period))
-    while the kernel loads it.
+    q_norm = (rowsumsq fp32 [B*Lq, H*dh/64] from ``gemm(..., rowsumsq=)`` OR the finalised factor fp32 [B*Lq] from
+    ``rmsnorm_rope_(..., rstd_of=)``, weight bf16 [H*dh], eps): q is the raw projection output and is RMS-normalised over
+    all heads (+ rotated with rope = (cos [period, H*dh], sin, period)) while the kernel loads it.
     out_segments = (tokens per segment, elements between segments): ``out`` is segment 0's [B, segment, H, dh] view of a
     buffer whose token axis is cut into such segments (the Ulysses return all-to-all's send buffer)."""
     _chk_bf16(q, k, v, out)
@@ -220,11 +231,17 @@ def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None,
     if q_norm is not None:
         ss, w, eps = q_norm
         nb = H * dh // 64
-        if ss.dtype != torch.float32 or ss.dim() != 2 or ss.shape != (B * Lq, nb) or ss.stride(1) != 1:
-            raise ValueError("ltxmi.attention: q_norm row sums must be fp32 [B*Lq, H*dh/64]")
         _chk_bf16(w)
-        a.q_rowsumsq, a.q_rowsumsq_stride_b, a.q_rowsumsq_stride_l = ss.data_ptr(), Lq * ss.stride(0), ss.stride(0)
-        a.q_rowsumsq_blocks, a.q_norm_weight, a.q_norm_eps = nb, w.data_ptr(), eps
+        if ss.dim() == 1:                                    # one finalised factor per row
+            if ss.dtype != torch.float32 or ss.shape != (B * Lq,) or ss.stride(0) != 1 or not ss.is_cuda:
+                raise ValueError("ltxmi.attention: q_norm row factors must be a contiguous fp32 [B*Lq]")
+            a.q_rstd, a.q_rstd_stride_b, a.q_rstd_stride_l = ss.data_ptr(), Lq, 1
+        else:
+            if ss.dtype != torch.float32 or ss.dim() != 2 or ss.shape != (B * Lq, nb) or ss.stride(1) != 1:
+                raise ValueError("ltxmi.attention: q_norm row sums must be fp32 [B*Lq, H*dh/64]")
+            a.q_rowsumsq, a.q_rowsumsq_stride_b, a.q_rowsumsq_stride_l = ss.data_ptr(), Lq * ss.stride(0), ss.stride(0)
+            a.q_rowsumsq_blocks = nb
+        a.q_norm_weight, a.q_norm_eps = w.data_ptr(), eps
         if rope is not None:
             cos, sin, period = rope
             _chk_bf16(cos, sin)

@@ -80,7 +80,10 @@ def _rope(o, cos, sin, period):
     return r
 
 
-def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, rope_period=0):
+def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, rope_period=0, rstd_of=None):
+    if rstd_of is not None:
+        ss, norm_dim, norm_eps, out = rstd_of
+        out.copy_(torch.rsqrt(ss.float().sum(-1) / norm_dim + norm_eps))
     x2 = _rows(x)
     o = x2.float()
     o = o * torch.rsqrt(o.pow(2).mean(-1, keepdim=True) + eps) * weight.float()

@@ -102,7 +102,11 @@ int main() {
     expect_fail(ltxmi_attention_fwd_bf16(&a, nullptr), "attention(fused q norm, no device)");
     a.Lq = a.Lk = 100;                                          // the generic kernel
     expect_fail(ltxmi_attention_fwd_bf16(&a, nullptr), "attention(fused q norm on a small shape, no device)");
-    a.q_rowsumsq = nullptr; a.q_norm_weight = nullptr; a.rope_cos = a.rope_sin = nullptr;
+    a.q_rowsumsq = nullptr; a.q_rstd = pf; a.q_rstd_stride_l = 1; a.q_rstd_stride_b = 100;   // the finalised row factor
+    expect_fail(ltxmi_attention_fwd_bf16(&a, nullptr), "attention(q_rstd, no device)");
+    a.q_norm_weight = nullptr;
+    expect_fail(ltxmi_attention_fwd_bf16(&a, nullptr), "attention(q_rstd without weight)", LTXMI_ERR_INVALID_ARG);
+    a.q_rstd = nullptr; a.rope_cos = a.rope_sin = nullptr;
     a.Lq = a.Lk = 4992; a.o_segment_len = 1000;                 // does not divide Lq
     expect_fail(ltxmi_attention_fwd_bf16(&a, nullptr), "attention(o segments not dividing Lq)");
     if (ltxmi_attention_fuses_qnorm(3, 32, 4992, 4992, 64, 0) != 1 || ltxmi_attention_fuses_qnorm(1, 32, 64, 64, 64, 1) != 1 ||
@@ -126,6 +130,9 @@ int main() {
     expect_fail(ltxmi_rmsnorm_rope_bf16(nullptr, 0, 0, 0, nullptr, 0.f, nullptr, nullptr, 0, 0, nullptr), "rmsnorm_rope(NULL)");
     expect_fail(ltxmi_rmsnorm_rope_bf16(p, 6144, 4992, 2048, p, 1e-6f, p, p, 2048, 4992, nullptr), "rmsnorm_rope(no device)");
     expect_fail(ltxmi_rmsnorm_rope_bf16(p, 6144, 4992, 2048, p, 1e-6f, p, nullptr, 2048, 4992, nullptr), "rmsnorm_rope(cos without sin)");
+    expect_fail(ltxmi_rmsnorm_rope_rstd_bf16(p, 6144, 4992, 2048, p, 1e-6f, p, p, 2048, 4992, nullptr, 32, 32, 2048, 1e-6f, pf, nullptr), "rmsnorm_rope_rstd(NULL sums)", LTXMI_ERR_INVALID_ARG);
+    expect_fail(ltxmi_rmsnorm_rope_rstd_bf16(p, 6144, 4992, 2048, p, 1e-6f, p, p, 2048, 4992, pf, 16, 32, 2048, 1e-6f, pf, nullptr), "rmsnorm_rope_rstd(ld < blocks)", LTXMI_ERR_INVALID_ARG);
+    expect_fail(ltxmi_rmsnorm_rope_rstd_bf16(p, 6144, 4992, 2048, p, 1e-6f, p, p, 2048, 4992, pf, 32, 32, 2048, 1e-6f, pf, nullptr), "rmsnorm_rope_rstd(no device)");
     expect_fail(ltxmi_qkv_norm_rope_pack_bf16(nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, 0.f, nullptr, nullptr, 0, 0, nullptr, nullptr), "pack(NULL)");
     expect_fail(ltxmi_qkv_norm_rope_pack_bf16(p, 6144, 3, 2496, 2048, 2, p, p, 1e-6f, p, p, 2048, 2496, p, nullptr), "pack(no device)");
     expect_fail(ltxmi_qkv_norm_rope_pack_bf16(p, 6144, 3, 2496, 2048, 3, p, p, 1e-6f, p, p, 2048, 2496, p, nullptr), "pack(P not dividing the heads)");

@@ -873,6 +873,18 @@ def test_attention_q_norm_and_rope_on_load(B, H, N, per_sample_tables):
     f5 = fused_in.view(B, N, 3, H, dh)
     fused = ops.attention(f5[:, :, 0], f5[:, :, 1], f5[:, :, 2], q_norm=(ss, wq, 1e-5), rope=(cos, sin, rows))
     check(fused, two_pass.float(), rel_l2=2e-3, maxrel=1.6e-2, what="q finished on load vs two passes")
+    # round 3: the row factor finalised by k's pass (one float per row, ltxmi_rmsnorm_rope_rstd_bf16) instead of the partial
+    # sums: k comes out bit-identical to its plain pass, the factor matches fp32, and attention matches the partial-sums form
+    k_in = qkv.clone()
+    rstd = torch.full((B * N,), float("nan"), dtype=torch.float32, device=DEV)
+    ops.rmsnorm_rope_(k_in[:, D:2 * D], wk, 1e-5, cos, sin, rows, rstd_of=(ss, D, 1e-5, rstd))
+    assert torch.equal(k_in[:, D:2 * D], ref[:, D:2 * D]) and torch.equal(k_in[:, :D], qkv[:, :D])
+    want = torch.rsqrt(qkv[:, :D].float().pow(2).mean(-1) + 1e-5)
+    assert float(((rstd - want) / want).abs().max()) < 1e-5
+    k5 = k_in.view(B, N, 3, H, dh)
+    fused_r = ops.attention(k5[:, :, 0], k5[:, :, 1], k5[:, :, 2], q_norm=(rstd, wq, 1e-5), rope=(cos, sin, rows))
+    check(fused_r, fused.float(), rel_l2=5e-4, maxrel=8e-3, what="q factor finalised per row vs partial sums")
+    check(fused_r, two_pass.float(), rel_l2=2e-3, maxrel=1.6e-2, what="q finished on load (row factor) vs two passes")
     # a band of rows against the oracle (fp32 norm + RoPE + attention on the same bf16 inputs)
     sel = slice(N - 200, N)
     q32 = qkv[:, :D].float().cpu().view(B, N, D)

@@ -20,6 +20,13 @@
 //     staging registers, no ds_write, and no VMEM/LDS-store issue slots taken from the softmax.
 //     The swizzles of both LDS images (attention.hip) are applied to the per-lane SOURCE address.
 //   * One s_barrier per key tile.
+//   * (round 3) A segment has no serial head any more.  What used to sit in front of the 16 chunks with the matrix pipe idle
+//     (round 2 stamps: 28 % of an iteration) now rides inside the chunks: every chunk requests the LDS operand of the MFMA
+//     four chunks later (K fragments, then V^T fragments, then the first K fragments of the NEXT segment's slot), the tile
+//     maximum of the block whose scores have just been produced is folded two scores at a time as a running v_max3 chain
+//     in those same chunks, and the row sums (ones-MFMA) of a P fragment are issued in the block's own softmax segment
+//     as soon as the fragment is packed.  What is left between two chunk streams is the running-max update and the
+//     rarely taken rescale branch.
 #include <type_traits>
 
 #include "attention.h"
@@ -62,6 +69,7 @@ struct Blk {
     bf16x8 q[4];     // Q^T fragments (B operand of the QK^T product), k-steps of 16
     f32x4 l;         // row sums (ones-MFMA accumulator): lanes 0..15, registers 0 / 1 = query n / n + 16
     float m;         // running row max (raw scores)
+    float mt;        // maximum of the scores in s (this block's pending tile), over both lane halves
 };
 
 struct Lane {
@@ -71,32 +79,27 @@ struct Lane {
     int v_rd;        // byte offset of this lane's transposed-read address inside a V slot
 };
 
-// One segment: VALU = softmax of X's pending scores (X.s -> X.pf, X.m, rescale of X.o / X.l);
-// matrix pipe = Y's row sums and PV with Y's pending P against the V slot `vs`, and Y's next
-// scores against the K slot `ks`.
+// One segment: VALU = softmax of X's pending scores (X.s -> X.pf, X.m, rescale of X.o / X.l) and the running maximum of
+// the scores Y produces; matrix pipe = Y's next scores against the K fragments kf (read during the previous segment), PV
+// with Y's pending P against the V slot `vs`, and the row sums of the P fragments as they become complete.
+// kf is both input (the fragments of this segment's K slot) and output (refilled from `ks_next`, the next segment's K
+// slot, one fragment per chunk behind the PV MFMAs).
+// key0_y: first key of the tile whose scores Y receives in this segment; when that tile is the ragged last one its keys past
+// Lk are masked where the scores are produced -- a wave-uniform branch, not a template instance: with three or four copies
+// of the iteration body behind different call sites hipcc's register allocator spilled 170 registers at the merges.
 // hook(j) runs once per chunk j, right behind the chunk's MFMA: the kernel uses it to issue its LDS-DMA pieces one at a
 // time in the shadow of an MFMA instead of as a burst of four behind the barrier
-template <bool TAIL, typename Hook>
-__device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const char* vs, const Lane& L,
-                                        const bf16x8& ones, float c, int key0, int Lk, Stamps& st, int st0, Hook&& hook) {
-    // ---- head: K fragments of the whole slot (8 x ds_read_b128), Y's row sums, X's row max
-    bf16x8 kf[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        kf[j] = *(const bf16x8*)(ks + L.k_rd[j >> 2] + (((2 * (j & 3) + L.hh) ^ L.k_sw0) << 4));
+template <typename Hook>
+__device__ __forceinline__ void segment(Blk& X, Blk& Y, bf16x8 (&kq)[4], const char* ks_cur, const char* ks_next, const char* vs,
+                                        const Lane& L, const bf16x8& ones, float c, int key0_y, int Lk, Stamps& st, int st0,
+                                        Hook&& hook) {
+    // ---- what is left of the head: X's running max and the rarely taken, wave-uniform O-wide rescale (the running max
+    // settles after the first few tiles)
+#ifdef LTXMI_PIPE_SUMS_IN_HEAD
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp) Y.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Y.pf[sp]), Y.l, 0, 0, 0);
-
-    if (TAIL) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = key0 + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * L.hh;
-                if (key >= Lk) X.s[kb][e] = -INFINITY;
-            }
-    }
-    float mt;
+#endif
+#ifdef LTXMI_PIPE_MAX_IN_HEAD
     {
         auto max3 = [](float a, float b, float c3) { return fmaxf(fmaxf(a, b), c3); };
         float l1[11];
@@ -107,13 +110,12 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
         }
         l1[10] = max3(X.s[0][15], X.s[1][15], l1[0]);
         const float a = max3(l1[1], l1[2], l1[3]), b2 = max3(l1[4], l1[5], l1[6]), c2 = max3(l1[7], l1[8], l1[9]);
-        mt = fmaxf(max3(a, b2, c2), l1[10]);
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-        mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        const float mtx = fmaxf(max3(a, b2, c2), l1[10]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mtx), __float_as_uint(mtx), false, false);
+        X.mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
-    const float m_new = fmaxf(X.m, mt);
-    // the O-wide rescale is a real, rarely taken wave-uniform branch (the running max settles after
-    // the first few tiles)
+#endif
+    const float m_new = fmaxf(X.m, X.mt);
     if (__any(m_new != X.m)) {
         asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
         const float alpha = fast_exp2((X.m - m_new) * c);
@@ -129,11 +131,30 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
     __builtin_amdgcn_sched_barrier(0);
     STAMP(st0);
 
-    // ---- 16 chunks: one 32x32x16 MFMA, the LDS reads of a later MFMA, and two scores' worth of
-    // softmax (2 fma, 2 exp2, 1 cvt_pk) each
-    bf16x8 vf[8];
+    // ---- 16 chunks: one 32x32x16 MFMA, the LDS read(s) of the operand of the MFMA FOUR chunks later (a rolling window of
+    // ~5 fragments in registers instead of a whole slot's eight), and two scores' worth of softmax (2 fma, 2 exp2, 1 cvt_pk)
+    auto kread = [&](const char* slot, int i) __attribute__((always_inline)) {
+        return *(const bf16x8*)(slot + L.k_rd[i >> 2] + (((2 * (i & 3) + L.hh) ^ L.k_sw0) << 4));
+    };
+    auto vread = [&](int i) __attribute__((always_inline)) {
+        // V^T fragment of PV MFMA i (k-step sp = i >> 1, head-dim block d = i & 1)
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const char* base = vs + L.v_rd + (2 * (i >> 1) * 2 + (i & 1)) * 512;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 2 * 512));
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, both);
+    };
+    bf16x8 f[16];                                   // f[j] = the LDS operand of chunk j's MFMA (static indices: registers)
+#ifdef LTXMI_PIPE_K_IN_HEAD
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = kread(ks_cur, i);
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = kq[i];
+#endif
     float pp0 = 0.f, pp1 = 0.f;
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    float mt = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         if (j < 8) {
@@ -142,17 +163,28 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
 #pragma unroll
                 for (int e = 0; e < 16; ++e) Y.s[kb][e] = 0.f;
             }
-            Y.s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], Y.q[s], Y.s[kb], 0, 0, 0);
-            // V^T fragment of PV MFMA j (k-step sp = j >> 1, head-dim block d = j & 1)
-            const char* base = vs + L.v_rd + (2 * (j >> 1) * 2 + (j & 1)) * 512;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 2 * 512));
-            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            vf[j] = __builtin_bit_cast(bf16x8, both);
+            Y.s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], Y.q[s], Y.s[kb], 0, 0, 0);
         } else {
             const int jj = j - 8, sp = jj >> 1, d = jj & 1;
-            Y.o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jj], __builtin_bit_cast(bf16x8, Y.pf[sp]), Y.o[d], 0, 0, 0);
+            Y.o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], __builtin_bit_cast(bf16x8, Y.pf[sp]), Y.o[d], 0, 0, 0);
         }
+#ifdef LTXMI_PIPE_K_IN_HEAD
+        if (j < 8) f[8 + j] = vread(j);
+#else
+        {
+            const int cn = j + 4;                   // the chunk whose operand is requested now
+            if (cn < 8) f[cn] = kread(ks_cur, cn);
+            else if (cn < 16) f[cn] = vread(cn - 8);
+            else kq[cn - 16] = kread(ks_next, cn - 16);
+        }
+#endif
+        // row sums on the matrix pipe (one 16x16x32 against the masked all-ones operand per P fragment): Y's last fragment
+        // of its previous softmax here, X's fragments 0..2 right after the chunk that packed their last pair
+#ifndef LTXMI_PIPE_SUMS_IN_HEAD
+        if (j == 1) Y.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Y.pf[3]), Y.l, 0, 0, 0);
+        if (j == 5 || j == 9 || j == 13)
+            X.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, X.pf[(j - 5) >> 2]), X.l, 0, 0, 0);
+#endif
         hook(j);
         // softmax of two scores; the pair is packed one chunk later (a v_cvt_pk right behind the v_exp
         // it reads costs an s_nop: transcendental -> VALU hazard)
@@ -169,9 +201,32 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
         }
         pp0 = p0;
         pp1 = p1;
+        // running maximum of Y's new scores, four per chunk (Y.s[0] is complete since chunk 3, Y.s[1] since chunk 7)
+        if (j >= 8) {
+            const int kbm = (j - 8) >> 2, em = 4 * ((j - 8) & 3);
+            if (em == 0 && key0_y + KV_TILE > Lk) {
+                asm volatile("; ragged key tile (kept a real branch)" ::: "memory");
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = key0_y + 32 * kbm + (e & 3) + 8 * (e >> 2) + 4 * L.hh;
+                    if (key >= Lk) Y.s[kbm][e] = -INFINITY;
+                }
+            }
+#ifndef LTXMI_PIPE_MAX_IN_HEAD
+            mt = fmaxf(fmaxf(mt, Y.s[kbm][em]), Y.s[kbm][em + 1]);
+            mt = fmaxf(fmaxf(mt, Y.s[kbm][em + 2]), Y.s[kbm][em + 3]);
+            asm volatile("" : "+v"(mt));            // (pinned to this chunk, like the conversions)
+#endif
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     X.pf[3][3] = pack_bf16(pp0, pp1);
+#ifndef LTXMI_PIPE_MAX_IN_HEAD
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+        Y.mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+#endif
     STAMP(st0 + 1);
 }
 
@@ -275,8 +330,6 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
         dma2(v_desc, dst, v_voff[0] + toff, v_voff[1] + toff);
     };
 
-    const int nt = (p.Lk + KV_TILE - 1) / KV_TILE;
-    const int n_full = p.Lk / KV_TILE;
     dma_k(0); dma_v(0); dma_k(1); dma_v(1); dma_k(2);
 
     // ---- per-lane LDS read offsets (attention.hip's images)
@@ -303,9 +356,9 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
         for (int s = 0; s < 4; ++s) X.q[s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * L.hh);
         if (p.q_on_load()) {
             // fused K1: q is the raw projection output.  q_norm (RMSNorm over all H * dh channels, attention.py:478-479,
-            // 1040-1041) from the row's factor (finalised per row by k's pass, or the projection GEMM's partial sums of
-            // squares), x weight, then the interleaved-pair RoPE on the flat channel axis (:960-975, 1053-1055) -- the
-            // arithmetic of rmsnorm_rope_kernel (rowops.hip), one rounding to bf16 at the end.
+            // 1040-1041) from the row's factor (or the projection GEMM's partial sums of squares), x weight, then the
+            // interleaved-pair RoPE on the flat channel axis (:960-975, 1053-1055) -- the arithmetic of rmsnorm_rope_kernel
+            // (rowops.hip), one rounding to bf16 at the end.
             const float rstd = p.q_row_rstd(b, q_ld, p.H * DH);
             const int64_t trow = (int64_t)b * p.rope_sb + (int64_t)q_ld * p.rope_sl;
 #pragma unroll
@@ -330,6 +383,7 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
             }
         }
         X.m = -INFINITY;
+        X.mt = -INFINITY;
         X.l = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) X.pf[i] = u32x4{0u, 0u, 0u, 0u};
@@ -351,9 +405,33 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    // A wave whose 64 query rows all lie past Lq (the half-empty last query tile of a (batch, head): N = 4992 = 19.5 x 256)
-    // keeps the workgroup's K/V stream going -- its LDS-DMA pieces, the barriers, the counted waits -- and computes nothing,
-    // so its SIMD partner (a wave of the other resident workgroup) gets the pipes to itself.
+    const int nt = (p.Lk + KV_TILE - 1) / KV_TILE;
+    const int n_full = p.Lk / KV_TILE;
+    // S_A(0), its maximum, and the fragments of K slot 0 kept for segment 1 of iteration 0 (block B's first scores)
+    bf16x8 kq[4];                                     // K fragments 0..3 of the coming segment's slot
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        const bf16x8 kfj = *(const bf16x8*)(kring + L.k_rd[j >> 2] + (((2 * (j & 3) + L.hh) ^ L.k_sw0) << 4));
+        A.s[j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfj, A.q[j & 3], A.s[j >> 2], 0, 0, 0);
+        if (j < 4) kq[j] = kfj;
+    }
+    {
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (n_full == 0) {
+                    const int key = 32 * kb2 + (e & 3) + 8 * (e >> 2) + 4 * L.hh;
+                    if (key >= p.Lk) A.s[kb2][e] = -INFINITY;
+                }
+                mt = fmaxf(mt, A.s[kb2][e]);
+            }
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+        A.mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+
+    const float c = p.scale_log2e;
     Stamps st;
 #ifdef LTXMI_ATTN_STAMPS
     for (int i = 0; i < 8; ++i) st.acc[i] = 0;
@@ -361,64 +439,45 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     unsigned long long rt0_;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0_)::"memory");
 #endif
-    const bool wave_idle = qt * Q_PER_WG + wave * 64 >= p.Lq;
-    if (wave_idle) {
-        for (int t = 0; t < nt; ++t) {
-            __builtin_amdgcn_s_barrier();
-            dma_k(t + 3);
-            dma_v(t + 2);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
-    } else {
-        // S_A(0)
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 kf = *(const bf16x8*)(kring + L.k_rd[kb2] + (((2 * s + L.hh) ^ L.k_sw0) << 4));
-                A.s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, A.q[s], A.s[kb2], 0, 0, 0);
-            }
-
-        const float c = p.scale_log2e;
-        using no_tail = std::integral_constant<bool, false>;
-        using with_tail = std::integral_constant<bool, true>;
-        auto iteration = [&](int t, auto tail_tag) {
-            constexpr bool TAIL = decltype(tail_tag)::value;
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP(0);
-            STAMP(1);
-            // this iteration's four LDS-DMA pieces -- K(t+3) into the slot K(t-1) left at this barrier, V(t+2) into V(t-2)'s --
-            // go out one at a time behind an MFMA (chunks 3 and 11 of each segment), in this order (the counted wait below
-            // relies on it): a burst of four behind the barrier cost ~200 cycles per iteration with the wave issuing nothing else
-            segment<TAIL>(A, Bk, kring + (t & 3) * TILE_BYTES, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2,
-                          [&](int j) { if (j == 3) dma_k1(t + 3, 0); else if (j == 11) dma_k1(t + 3, 1); });
-            segment<TAIL>(Bk, A, kring + ((t + 1) & 3) * TILE_BYTES, vring + (t & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 4,
-                          [&](int j) { if (j == 3) dma_v1(t + 2, 0); else if (j == 11) dma_v1(t + 2, 1); });
-            // everything issued before this iteration's four pieces has landed: K(t+2), V(t+1)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP(6);
-        };
-        for (int t = 0; t < n_full; ++t) iteration(t, no_tail{});
-        if (n_full < nt) iteration(n_full, with_tail{});
-
+    // iteration t: segment 1 produces block B's scores of tile t, segment 2 block A's of tile t + 1 (tile nt: all keys out
+    // of range, never used)
+    for (int t = 0; t < nt; ++t) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(0);
+        STAMP(1);
+        // this iteration's four LDS-DMA pieces -- K(t+3) into the slot K(t-1) left at this barrier, V(t+2) into V(t-2)'s --
+        // go out one at a time behind an MFMA (chunks 3 and 11 of each segment), in this order (the counted wait below
+        // relies on it): a burst of four behind the barrier cost ~200 cycles per iteration with the wave issuing nothing else
+        const char* k_t = kring + (t & 3) * TILE_BYTES;
+        const char* k_t1 = kring + ((t + 1) & 3) * TILE_BYTES;
+        segment(A, Bk, kq, k_t, k_t1, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2,
+                [&](int j) { if (j == 3) dma_k1(t + 3, 0); else if (j == 11) dma_k1(t + 3, 1); });
+        segment(Bk, A, kq, k_t1, k_t1, vring + (t & 3) * TILE_BYTES, L, ones, c, (t + 1) * KV_TILE, p.Lk, st, 4,
+                [&](int j) { if (j == 3) dma_v1(t + 2, 0); else if (j == 11) dma_v1(t + 2, 1); });
+        // everything issued before this iteration's four pieces has landed: K(t+2), V(t+1)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(6);
     }
 
 #ifdef LTXMI_ATTN_STAMPS
     unsigned long long rt1_;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1_)::"memory");
-    if (g_attn_stamps && L.lane == 0 && blockIdx.x < 4096 && !wave_idle) {
+    if (g_attn_stamps && L.lane == 0 && blockIdx.x < 4096) {
         for (int i = 0; i < 7; ++i) g_attn_stamps[(blockIdx.x * 4 + wave) * 8 + i] = st.acc[i];
         // low 32 bits: key tiles; high 32 bits: elapsed s_memrealtime ticks (100 MHz) of the loop
         g_attn_stamps[(blockIdx.x * 4 + wave) * 8 + 7] = (unsigned long long)nt | ((rt1_ - rt0_) << 32);
     }
 #endif
-    // ---- drain: block B's last row sums and PV
-    if (!wave_idle) {
+    // ---- drain: block B's last P fragment's row sums and its PV
+    {
         const char* vs = vring + ((nt - 1) & 3) * TILE_BYTES;
+#ifdef LTXMI_PIPE_SUMS_IN_HEAD
 #pragma unroll
-        for (int sp = 0; sp < 4; ++sp) Bk.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Bk.pf[sp]), Bk.l, 0, 0, 0);
+        for (int sp = 0; sp < 3; ++sp) Bk.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Bk.pf[sp]), Bk.l, 0, 0, 0);
+#endif
+        Bk.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Bk.pf[3]), Bk.l, 0, 0, 0);
         typedef __attribute__((ext_vector_type(8))) short s16x8;
 #pragma unroll
         for (int sp = 0; sp < 4; ++sp)
