@@ -143,6 +143,9 @@ int ltxmi_rmsnorm_rope_rstd_bf16(void* x, int64_t ldx, int32_t rows, int32_t D, 
  * (strides in elements; lets q,k,v alias slices of one fused [B,L,3*H*dh] projection buffer).
  * key_bias: optional fp32 [B, Lk] added to the scaled scores (broadcast over heads and queries).
  * head_dim in {64, 128}; Lq, Lk >= 1 (ragged tails are masked inside the kernel).
+ * Kernels behind the entry point (chosen by shape, ltxmi_attention_kernel_id): the software-pipelined LDS-DMA kernels for
+ * large bias-free shapes (head_dim 64: two waves per SIMD; head_dim 128: one wave per SIMD with the whole register file)
+ * and the register-staged kernel for everything else (key bias, small shapes).
  * ------------------------------------------------------------------------------- */
 typedef struct ltxmi_attn_args {
     const void* q; int64_t q_stride_b, q_stride_l;
@@ -177,8 +180,11 @@ int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* args, void* stream);
  * ltxmi_rmsnorm_rope_bf16 on q as a pass of its own).  Since 0.2 every shape the entry point accepts qualifies. */
 int ltxmi_attention_fuses_qnorm(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias);
 /* Identifier (>= 0) of the kernel instance ltxmi_attention_fwd_bf16 runs for this shape, -1 if unsupported.  Shapes with
- * the same id get the same arithmetic per (batch, head, query row) -- e.g. B and B - 1 batch rows of one model call. */
-int ltxmi_attention_kernel_id(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias);
+ * the same id get the same arithmetic per (batch, head, query row) -- e.g. B and B - 1 batch rows of one model call.
+ * k_stride_l / v_stride_l (0.3): the token strides the call will pass -- the pipelined kernels (ids 3 and 6) address a
+ * (batch, head)'s keys with 32-bit byte offsets and hand shapes whose rows span 2 GiB or more to the other kernels. */
+int ltxmi_attention_kernel_id(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias,
+                              int64_t k_stride_l, int64_t v_stride_l);
 
 /* Ulysses send buffer in one pass (sequence-parallel self-attention, xdit_context_parallel.py:149-184 of the reference
  * for Wan; here for the LTX DiT): q/k RMSNorm(weight) + interleaved RoPE exactly as ltxmi_rmsnorm_rope_bf16 and v,

@@ -53,7 +53,16 @@ struct AttnParams {
 // attention_pipe.hip: software-pipelined self-attention (head_dim 64, no key bias).
 // Returns -1 when the shape is not taken (the caller then uses attention.hip's kernel).
 int launch_attn_pipe(AttnParams p, hipStream_t stream);
-// whether launch_attn_pipe takes this shape (the only kernel that can normalise q on load)
+// whether launch_attn_pipe takes this shape
 bool attn_pipe_takes(int B, int H, int Lq, int Lk, int head_dim, bool has_bias);
+// attention_pipe128.hip: the same for head_dim 128 (one 4-wave workgroup per CU, 512 registers per wave)
+int launch_attn_pipe128(AttnParams p, hipStream_t stream);
+bool attn_pipe128_takes(int B, int H, int Lq, int Lk, int head_dim, bool has_bias);
+// both pipelined kernels address a (batch, head)'s K / V rows through buffer descriptors with 32-bit byte offsets: the rows
+// of all key tiles (+ the ring's run-ahead) must span less than 2 GiB
+inline bool attn_pipe_span_ok(int Lk, int64_t k_sl, int64_t v_sl, int head_dim) {
+    const int64_t k_span = ((int64_t)(Lk + 4 * 64) * k_sl + head_dim) * 2, v_span = ((int64_t)(Lk + 4 * 64) * v_sl + head_dim) * 2;
+    return k_span < (1ll << 31) && v_span < (1ll << 31);
+}
 
 }  // namespace ltxmi

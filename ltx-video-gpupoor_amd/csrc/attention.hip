@@ -485,7 +485,8 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     p.o_seg = a->o_segment_len; p.o_sseg = a->o_stride_segment;
     LTXMI_REQUIRE(a->o_segment_len >= 0 && a->o_stride_segment % 8 == 0, LTXMI_ERR_INVALID_ARG,
                   "ltxmi_attention_fwd_bf16: bad output segment geometry");
-    const bool pipe_ok = attn_pipe_takes(a->B, a->H, a->Lq, a->Lk, a->head_dim, a->key_bias != nullptr);
+    const bool span_ok = attn_pipe_span_ok(a->Lk, a->k_stride_l, a->v_stride_l, a->head_dim);
+    const bool pipe_ok = span_ok && attn_pipe_takes(a->B, a->H, a->Lq, a->Lk, a->head_dim, a->key_bias != nullptr);
     if (a->q_rowsumsq || a->q_rstd) {
         LTXMI_REQUIRE(a->q_norm_weight && (((uintptr_t)a->q_norm_weight) & 15) == 0 &&
                           (a->q_rstd ? (((uintptr_t)a->q_rstd) & 3) == 0
@@ -512,17 +513,28 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
         if (wg256 >= 512 && !a->key_bias) return launch<64, false, ATTN_QB_BIG>(p, s);
         return a->key_bias ? launch<64, true, 1>(p, s) : launch<64, false, 1>(p, s);
     }
+    // head_dim 128, large self-attention: the one-wave-per-SIMD pipelined kernel (attention_pipe128.hip)
+    if (span_ok && attn_pipe128_takes(a->B, a->H, a->Lq, a->Lk, a->head_dim, a->key_bias != nullptr)) {
+        const int rc = launch_attn_pipe128(p, s);
+        if (rc != -1) return rc;
+    }
     return a->key_bias ? launch<128, true, 1>(p, s) : launch<128, false, 1>(p, s);
 }
 
-// Which kernel instance ltxmi_attention_fwd_bf16 runs for a shape (mirrors the dispatch above).  Two shapes with the
-// same id are computed with the same arithmetic per (batch, head, query row): what ltxmi.Transformer3DModel checks before
-// it runs a sub-batch of rows and claims bit-identity with the full batch.
-extern "C" int ltxmi_attention_kernel_id(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias) {
-    if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
-    if (head_dim == 128) return has_key_bias ? 5 : 4;
-    if (head_dim != 64) return -1;
-    if (attn_pipe_takes(B, H, Lq, Lk, head_dim, has_key_bias != 0)) return 3;
+// Which kernel instance ltxmi_attention_fwd_bf16 runs for a shape (mirrors the dispatch above, INCLUDING the 2 GiB span test
+// of the pipelined kernels, which depends on the key / value token strides).  Two shapes with the same id are computed with
+// the same arithmetic per (batch, head, query row): what ltxmi.Transformer3DModel checks before it runs a sub-batch of rows
+// and claims bit-identity with the full batch.
+extern "C" int ltxmi_attention_kernel_id(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias,
+                                         int64_t k_stride_l, int64_t v_stride_l) {
+    if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || k_stride_l <= 0 || v_stride_l <= 0) return -1;
+    if (head_dim != 64 && head_dim != 128) return -1;
+    const bool span_ok = attn_pipe_span_ok(Lk, k_stride_l, v_stride_l, head_dim);
+    if (head_dim == 128) {
+        if (span_ok && attn_pipe128_takes(B, H, Lq, Lk, head_dim, has_key_bias != 0)) return 6;
+        return has_key_bias ? 5 : 4;
+    }
+    if (span_ok && attn_pipe_takes(B, H, Lq, Lk, head_dim, has_key_bias != 0)) return 3;
     const int64_t wg256 = (int64_t)B * H * ((Lq + 255) / 256);
     if (wg256 >= 512 && !has_key_bias) return 2;
     return has_key_bias ? 1 : 0;

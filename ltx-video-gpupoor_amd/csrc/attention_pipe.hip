@@ -488,9 +488,7 @@ bool attn_pipe_takes(int B, int H, int Lq, int Lk, int head_dim, bool has_bias) 
 
 int launch_attn_pipe(AttnParams p, hipStream_t stream) {
     // the buffer descriptors address a (batch, head)'s K / V rows with 32-bit byte offsets
-    const int64_t k_span = ((int64_t)(p.Lk + 4 * pipe::KV_TILE) * p.k_sl + pipe::DH) * 2;
-    const int64_t v_span = ((int64_t)(p.Lk + 4 * pipe::KV_TILE) * p.v_sl + pipe::DH) * 2;
-    if (k_span >= (1ll << 31) || v_span >= (1ll << 31)) return -1;
+    if (!attn_pipe_span_ok(p.Lk, p.k_sl, p.v_sl, pipe::DH)) return -1;
     auto kern = pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC>;
     static unsigned long long lds_done = 0;
     if (const int rc = reserve_lds((const void*)kern, pipe::SMEM, &lds_done, "ltxmi_attention_fwd_bf16")) return rc;

@@ -62,7 +62,7 @@ SIGNATURES = {
                                               c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "ltxmi_attention_fwd_bf16": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "ltxmi_attention_fuses_qnorm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "ltxmi_attention_kernel_id": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "ltxmi_attention_kernel_id": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64]),
     "ltxmi_silu_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ltxmi_timestep_embedding_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ltxmi_stg_blend_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p]),

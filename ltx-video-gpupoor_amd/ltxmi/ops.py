@@ -184,9 +184,13 @@ def attention_fuses_qnorm(B, H, Lq, Lk, dh, has_key_bias=False):
     return bool(lib.ltxmi_attention_fuses_qnorm(B, H, Lq, Lk, dh, int(has_key_bias)))
 
 
-def attention_kernel_id(B, H, Lq, Lk, dh, has_key_bias=False):
-    """Which kernel instance ``attention`` runs for a shape: equal ids = the same arithmetic per (batch, head, row)."""
-    return int(lib.ltxmi_attention_kernel_id(B, H, Lq, Lk, dh, int(has_key_bias)))
+def attention_kernel_id(B, H, Lq, Lk, dh, has_key_bias=False, k_stride_l=None, v_stride_l=None):
+    """Which kernel instance ``attention`` runs for a shape: equal ids = the same arithmetic per (batch, head, row).
+    k_stride_l / v_stride_l: the token strides of k and v in elements (default: slices of the packed [.., 3 H dh]
+    projection, what AttnProcessor2_0 passes)."""
+    ks = 3 * H * dh if k_stride_l is None else k_stride_l
+    vs = ks if v_stride_l is None else v_stride_l
+    return int(lib.ltxmi_attention_kernel_id(B, H, Lq, Lk, dh, int(has_key_bias), ks, vs))
 
 
 def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None, rope=None, out_segments=None):

@@ -97,7 +97,7 @@ def attention_fuses_qnorm(B, H, Lq, Lk, dh, has_key_bias=False):
     return False            # the double keeps q's normalisation as a pass of its own (both forms are kernel-tested on the GPU)
 
 
-def attention_kernel_id(B, H, Lq, Lk, dh, has_key_bias=False):
+def attention_kernel_id(B, H, Lq, Lk, dh, has_key_bias=False, k_stride_l=None, v_stride_l=None):
     return 0
 
 

@@ -30,6 +30,8 @@ def main():
     if os.environ.get("AB_SHAPES") == "ulysses":       # heads per rank of the Ulysses mode at P = 2, 4, 8 (N 4992 and 13376)
         shapes = [(3, 16, 4992, 64, 10), (3, 8, 4992, 64, 10), (3, 4, 4992, 64, 10), (3, 16, 13376, 64, 5), (3, 8, 13376, 64, 5),
                   (3, 4, 13376, 64, 5)]
+    if os.environ.get("AB_SHAPES") == "dh128":         # config 4 (Wan 1.3B self-attention) and 13B-like LTX shapes
+        shapes = [(1, 12, 32760, 128, 3), (1, 32, 4992, 128, 10), (3, 32, 4992, 128, 5), (1, 32, 13376, 128, 3)]
     stream = torch.cuda.current_stream().cuda_stream
     for (B, H, N, dh, it) in shapes:
         qkv = torch.randn(B, N, 3, H, dh, device="cuda").to(torch.bfloat16)
