@@ -19,6 +19,8 @@
 //     softmax segment as soon as the fragment is packed.  (At head_dim 64, two waves per SIMD, the same restructuring was
 //     measured 2 % SLOWER -- profiles/r03_attn_headless_variants.log: a partner wave already covers the heads there and the
 //     chunks are issue-bound.  Here the VALU has slack and there is no partner.)
+#include <type_traits>
+
 #include "attention.h"
 
 namespace ltxmi {
@@ -30,7 +32,7 @@ constexpr int KV_TILE = 64;
 constexpr int ROW_BYTES = DH * 2;                // 256
 constexpr int TILE_BYTES = KV_TILE * DH * 2;     // 16 KiB: one K or V tile
 constexpr int RING = 4;
-constexpr int SMEM = 2 * RING * TILE_BYTES;      // K ring | V ring = 128 KiB
+constexpr int SMEM = 2 * RING * TILE_BYTES;      // K ring | V ring = 128 KiB (+ 16 B: the redo flag)
 constexpr int Q_PER_WG = 256;                    // 4 waves x 2 blocks x 32 rows
 constexpr int NS = DH / 16;                      // k-steps of a QK^T product (8)
 constexpr int ND = DH / 32;                      // 32-row blocks of O^T (4)
@@ -49,8 +51,8 @@ struct Blk {
 
 struct Lane {
     int lane, r, hh;
-    int k_rd;        // byte offset of K row r inside a K slot (row 32 + r: + 32 * ROW_BYTES)
-    int k_sw;        // swizzle of that row (and of row 32 + r)
+    int koff[8];     // byte offset inside a K slot of this lane's 16 bytes of row r for k-step s (row 32 + r: + 32 * ROW_BYTES):
+                     // r * 256 + ((2 s + hh) ^ (r & 15)) * 16 -- kept in registers: every read is then base + offset + immediate
     int v_rd;        // byte offset of this lane's transposed-read address inside a V sub-tile
 };
 
@@ -59,7 +61,7 @@ struct Lane {
 // (key >> 3) * 4 + (col >> 5) -- attention.hip's image with four column blocks instead of two.
 __device__ __forceinline__ bf16x8 kread(const char* slot, const Lane& L, int i) {
     // fragment i: key block kb = i >> 3 (rows 32 kb + r), k-step s = i & 7 (head-dim 16 s + 8 hh ..)
-    return *(const bf16x8*)(slot + L.k_rd + (i >> 3) * (32 * ROW_BYTES) + (((2 * (i & 7) + L.hh) ^ L.k_sw) << 4));
+    return *(const bf16x8*)(slot + L.koff[i & 7] + (i >> 3) * (32 * ROW_BYTES));
 }
 __device__ __forceinline__ bf16x8 vread(const char* slot, const Lane& L, int i) {
     // V^T fragment of PV MFMA i: k-step sp = i >> 2 (keys 16 sp ..), head-dim block d = i & 3
@@ -71,26 +73,66 @@ __device__ __forceinline__ bf16x8 vread(const char* slot, const Lane& L, int i) 
     return __builtin_bit_cast(bf16x8, both);
 }
 
+// Register placement is pinned by hand.  The state of two blocks is ~300 registers; what only the matrix pipe touches --
+// the O^T accumulators (2 x 64) and the Q^T fragments (2 x 32) -- lives in the accumulation registers (AGPRs), everything the
+// VALU works on (scores, P, LDS operands, softmax state) in the 256 architectural VGPRs.  hipcc cannot be talked into that
+// split through the MFMA builtins (it put the Q^T fragments and LDS offsets into AGPRs and copied four registers in front
+// of every QK^T MFMA: ~110 v_accvgpr moves per key tile on a loop whose one wave per SIMD is issue-bound), so the loop's
+// MFMAs are issued from inline asm with "a" / "v" constraints.  hipcc does not know these statements are MFMAs and pads no
+// hazards around them: every use of their results by the VALU is a segment away (the scores), and operands written by the
+// VALU (P fragments) are a chunk or more old when an MFMA reads them.
+//
+// The running-max RESCALE of O^T is VALU work on the accumulators, and ANY such code inside the loop -- however rarely
+// executed -- makes hipcc route one block's 64 accumulators through VGPRs on the hot path (64 v_accvgpr_write per key tile).
+// So the loop exists twice: the EXACT form (rescale whenever a row maximum grows) runs the first two key tiles, where the
+// maxima are still settling; the STEADY form then keeps each row's reference fixed -- P = 2^((s - m) c) may exceed 1, which
+// costs nothing in fp32 / bf16 floating point as long as it cannot overflow -- and contains no rescale at all, only a check
+// that no score has outgrown its reference by more than 2^STEADY_MAX_LOG2.  A workgroup in which that ever happens (scores
+// jumping by > 69 nats after the first 128 keys) redoes its item with the exact form throughout.
+__device__ __forceinline__ void mfma_s0(f32x16& acc, const bf16x8& k, const bf16x8& q) {      // acc = K Q^T (first k-step)
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void mfma_s(f32x16& acc, const bf16x8& k, const bf16x8& q) {       // acc += K Q^T
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void mfma_o(f32x16& acc, const bf16x8& vt, const bf16x8& pt) {     // acc += V^T P^T
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(vt), "v"(pt));
+}
+template <int N>
+__device__ __forceinline__ void settle_o(f32x16 (&o)[N]) {
+    // 16-pass MFMA result -> v_accvgpr_read / VALU: 18 wait states, software-inserted; the asm "uses" every accumulator so
+    // that no read of them can be scheduled in front of it
+    static_assert(N == 4, "four O^T blocks");
+    asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o[0]), "+a"(o[1]), "+a"(o[2]), "+a"(o[3]));
+}
+constexpr float STEADY_MAX_LOG2 = 100.0f;        // a score may exceed its row's reference by this many bits before the redo
+
 // One segment: VALU = softmax of X's pending scores (X.s -> X.pf, X.m, rescale of X.o / X.l) and the running maximum of the
 // scores Y produces; matrix pipe = Y's next scores (kq: fragments 0..3 of this segment's K slot, read during the previous
 // segment; the rest from ks_cur), PV with Y's pending P against the V slot vs, and the row sums of the P fragments as they
 // complete.  On return kq holds fragments 0..3 of ks_next.  key0_y: first key of the tile whose scores Y receives; a
 // ragged tile is masked where its scores are produced (a wave-uniform branch).  hook(j): the kernel's LDS-DMA issue points.
-template <typename Hook>
+template <bool EXACT, typename Hook>
 __device__ __forceinline__ void segment(Blk& X, Blk& Y, bf16x8 (&kq)[4], const char* ks_cur, const char* ks_next, const char* vs,
-                                        const Lane& L, const bf16x8& ones, float c, int key0_y, int Lk, Hook&& hook) {
-    const float m_new = fmaxf(X.m, X.mt);
-    // the O-wide rescale is a real, rarely taken wave-uniform branch (the running max settles after the first few tiles)
-    if (__any(m_new != X.m)) {
-        asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
-        const float alpha = fast_exp2((X.m - m_new) * c);
-        X.l[0] *= alpha;
-        X.l[1] *= __shfl(alpha, (L.lane + 16) & 63, 64);
+                                        const Lane& L, const bf16x8& ones, float c, int key0_y, int Lk, bool& outgrown, Hook&& hook) {
+    if (EXACT) {
+        const float m_new = fmaxf(X.m, X.mt);
+        // the O-wide rescale: a real wave-uniform branch
+        if (__any(m_new != X.m)) {
+            asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
+            const float alpha = fast_exp2((X.m - m_new) * c);
+            X.l[0] *= alpha;
+            X.l[1] *= __shfl(alpha, (L.lane + 16) & 63, 64);
+            settle_o(X.o);
 #pragma unroll
-        for (int d = 0; d < ND; ++d)
+            for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) X.o[d][e] *= alpha;
-        X.m = m_new;
+                for (int e = 0; e < 16; ++e) X.o[d][e] *= alpha;
+            X.m = m_new;
+        }
+    } else {
+        // steady form: the reference stays; only watch for a score that would overflow against it
+        outgrown = outgrown || __any((X.mt - X.m) * c > STEADY_MAX_LOG2);
     }
     const float nmoff = -X.m * c;
     __builtin_amdgcn_sched_barrier(0);
@@ -104,14 +146,11 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, bf16x8 (&kq)[4], const c
     for (int j = 0; j < NCH; ++j) {
         if (j < 2 * NS) {
             const int kb = j / NS, s = j % NS;
-            if (s == 0) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) Y.s[kb][e] = 0.f;
-            }
-            Y.s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], Y.q[s], Y.s[kb], 0, 0, 0);
+            if (s == 0) mfma_s0(Y.s[kb], f[j], Y.q[s]);
+            else mfma_s(Y.s[kb], f[j], Y.q[s]);
         } else {
             const int jj = j - 2 * NS, sp = jj / ND, d = jj % ND;
-            Y.o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], __builtin_bit_cast(bf16x8, Y.pf[sp]), Y.o[d], 0, 0, 0);
+            mfma_o(Y.o[d], f[j], __builtin_bit_cast(bf16x8, Y.pf[sp]));
         }
         {
             const int cn = j + 4;                   // the chunk whose operand is requested now
@@ -246,11 +285,9 @@ __global__ __launch_bounds__(256, 1) void attn_pipe128_kernel(AttnParams p) {
     };
 
     const int nt = (p.Lk + KV_TILE - 1) / KV_TILE;
-    dma_k(0); dma_v(0); dma_k(1); dma_v(1); dma_k(2);
-
     // ---- per-lane LDS read offsets
-    L.k_rd = L.r * ROW_BYTES;
-    L.k_sw = L.r & 15;                              // swz(32 + r) == swz(r)
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) L.koff[s8] = L.r * ROW_BYTES + (((2 * s8 + L.hh) ^ (L.r & 15)) << 4);   // swz(32 + r) == swz(r)
     {
         const int g16 = L.lane >> 4, i16 = L.lane & 15;
         L.v_rd = (4 * (g16 >> 1) + (i16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
@@ -308,78 +345,106 @@ __global__ __launch_bounds__(256, 1) void attn_pipe128_kernel(AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) X.s[kb][e] = 0.f;
     };
-    init(A, 0);
-    init(Bk, 1);
-    {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = 0; i < TILE_BYTES / (256 * 16); ++i) *(u32x4*)(vring + 3 * TILE_BYTES + (i * 256 + tid) * 16) = z;
-    }
-    // (the builtin, not asm: hipcc must KNOW the Q loads have landed, or it waits for them with a counted vmcnt at their
-    // first use inside the loop -- which then drains the LDS-DMA ring every iteration)
-    __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-
-    // S_A(0), its maximum, and fragments 0..3 of K slot 0 kept for segment 1 of iteration 0 (block B's first scores)
-    bf16x8 kq[4];
-#pragma unroll
-    for (int j = 2 * NS - 1; j >= 0; --j) {
-        const bf16x8 kfj = kread(kring, L, j);
-        A.s[j / NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfj, A.q[j % NS], A.s[j / NS], 0, 0, 0);
-        if (j < 4) kq[j] = kfj;
-    }
-    {
-        float mt = -INFINITY;
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                if (p.Lk < KV_TILE) {
-                    const int key = 32 * kb2 + (e & 3) + 8 * (e >> 2) + 4 * L.hh;
-                    if (key >= p.Lk) A.s[kb2][e] = -INFINITY;
-                }
-                mt = fmaxf(mt, A.s[kb2][e]);
-            }
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-        A.mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-
     const float c = p.scale_log2e;
-    // iteration t: segment 1 produces block B's scores of tile t, segment 2 block A's of tile t + 1 (tile nt: every key out of
-    // range, never used).  This iteration's eight LDS-DMA pieces -- K(t+3) into the slot K(t-1) left at this barrier, V(t+2)
-    // into V(t-2)'s -- go out one at a time behind an MFMA, in this order (the counted wait below relies on it).
-    for (int t = 0; t < nt; ++t) {
+    volatile int* redo_flag = (volatile int*)(smem + SMEM);         // one word behind the rings
+    if (tid == 0) *redo_flag = 0;
+    bool outgrown = false;
+    // attempt 0: exact form for the first two key tiles, steady form for the rest; attempt 1 (only if some wave of the
+    // workgroup saw a score outgrow its reference): the whole item again in the exact form
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        dma_k(0); dma_v(0); dma_k(1); dma_v(1); dma_k(2);
+        init(A, 0);
+        init(Bk, 1);
+        // (Q^T fragments pinned to the accumulation registers: every use below is an "a" operand)
+#pragma unroll
+        for (int s8 = 0; s8 < NS; ++s8) {
+            asm volatile("" : "+a"(A.q[s8]));
+            asm volatile("" : "+a"(Bk.q[s8]));
+        }
+        {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < TILE_BYTES / (256 * 16); ++i) *(u32x4*)(vring + 3 * TILE_BYTES + (i * 256 + tid) * 16) = z;
+        }
+        // (the builtin, not asm: hipcc must KNOW the Q loads have landed, or it waits for them with a counted vmcnt at their
+        // first use inside the loop -- which then drains the LDS-DMA ring every iteration)
+        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const char* k_t = kring + (t & 3) * TILE_BYTES;
-        const char* k_t1 = kring + ((t + 1) & 3) * TILE_BYTES;
-        segment(A, Bk, kq, k_t, k_t1, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk,
-                [&](int j) { if ((j & 7) == 3) dma_k1(t + 3, j >> 3); });
-        segment(Bk, A, kq, k_t1, k_t1, vring + (t & 3) * TILE_BYTES, L, ones, c, (t + 1) * KV_TILE, p.Lk,
-                [&](int j) { if ((j & 7) == 3) dma_v1(t + 2, j >> 3); });
-        // everything issued before this iteration's eight pieces has landed: K(t+2), V(t+1)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+
+        // S_A(0), its maximum, and fragments 0..3 of K slot 0 kept for segment 1 of iteration 0 (block B's first scores)
+        bf16x8 kq[4];
+#pragma unroll
+        for (int j = 0; j < 2 * NS; ++j) {
+            const bf16x8 kfj = kread(kring, L, j);
+            if (j % NS == 0) mfma_s0(A.s[j / NS], kfj, A.q[j % NS]);
+            else mfma_s(A.s[j / NS], kfj, A.q[j % NS]);
+            if (j < 4) kq[j] = kfj;
+        }
+        {
+            float mt = -INFINITY;
+            // (MFMA results read by the VALU: the hazard window is not padded for asm MFMAs)
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(A.s[0]), "+v"(A.s[1]));
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (p.Lk < KV_TILE) {
+                        const int key = 32 * kb2 + (e & 3) + 8 * (e >> 2) + 4 * L.hh;
+                        if (key >= p.Lk) A.s[kb2][e] = -INFINITY;
+                    }
+                    mt = fmaxf(mt, A.s[kb2][e]);
+                }
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+            A.mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+
+        // iteration t: segment 1 produces block B's scores of tile t, segment 2 block A's of tile t + 1 (tile nt: every key
+        // out of range, never used).  This iteration's eight LDS-DMA pieces -- K(t+3) into the slot K(t-1) left at this
+        // barrier, V(t+2) into V(t-2)'s -- go out one at a time behind an MFMA, in this order (the counted wait relies on it).
+        auto iteration = [&](int t, auto exact_tag) __attribute__((always_inline)) {
+            constexpr bool EXACT = decltype(exact_tag)::value;
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const char* k_t = kring + (t & 3) * TILE_BYTES;
+            const char* k_t1 = kring + ((t + 1) & 3) * TILE_BYTES;
+            segment<EXACT>(A, Bk, kq, k_t, k_t1, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, outgrown,
+                           [&](int j) { if ((j & 7) == 3) dma_k1(t + 3, j >> 3); });
+            segment<EXACT>(Bk, A, kq, k_t1, k_t1, vring + (t & 3) * TILE_BYTES, L, ones, c, (t + 1) * KV_TILE, p.Lk, outgrown,
+                           [&](int j) { if ((j & 7) == 3) dma_v1(t + 2, j >> 3); });
+            // everything issued before this iteration's eight pieces has landed: K(t+2), V(t+1)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const int t_exact = attempt == 0 ? (nt < 2 ? nt : 2) : nt;
+        int t = 0;
+        for (; t < t_exact; ++t) iteration(t, std::integral_constant<bool, true>{});
+        for (; t < nt; ++t) iteration(t, std::integral_constant<bool, false>{});
+
+        // ---- drain: block B's last P fragment's row sums and its PV
+        {
+            const char* vs = vring + ((nt - 1) & 3) * TILE_BYTES;
+            Bk.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Bk.pf[3]), Bk.l, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4 * ND; ++i) mfma_o(Bk.o[i % ND], vread(vs, L, i), __builtin_bit_cast(bf16x8, Bk.pf[i / ND]));
+        }
+        // the out-of-range pieces of tiles >= nt are still landing (as zeros): drain them before the rings are reused (as
+        // the output scratch, or by the redo's stream); and agree on the redo
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (outgrown && L.lane == 0) *redo_flag = 1;
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        const int redo = *redo_flag;
+        __builtin_amdgcn_s_barrier();
+        if (attempt == 1 || redo == 0) break;
+        outgrown = false;
     }
 
-    // ---- drain: block B's last P fragment's row sums and its PV
-    {
-        const char* vs = vring + ((nt - 1) & 3) * TILE_BYTES;
-        Bk.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Bk.pf[3]), Bk.l, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4 * ND; ++i)
-            Bk.o[i % ND] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vread(vs, L, i), __builtin_bit_cast(bf16x8, Bk.pf[i / ND]), Bk.o[i % ND], 0, 0, 0);
-    }
-    // the out-of-range pieces of tiles >= nt are still landing (as zeros): drain them before the rings become the output
-    // scratch
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue: O = O^T / l, through a per-wave LDS scratch so that rows leave whole (attention.hip): 32 rows of 256 B,
     // 16-byte chunks XOR-swizzled by the row
     auto store = [&](Blk& X, int blk) {
+        settle_o(X.o);
         const float l0 = __shfl(X.l[0], L.r & 15, 64), l1 = __shfl(X.l[1], L.r & 15, 64);
         const float inv = 1.0f / ((L.r & 16) ? l1 : l0);
         char* scr = smem + (wave * 2 + blk) * (32 * ROW_BYTES);
@@ -424,10 +489,10 @@ int launch_attn_pipe128(AttnParams p, hipStream_t stream) {
     if (!attn_pipe_span_ok(p.Lk, p.k_sl, p.v_sl, pipe128::DH)) return -1;
     auto kern = pipe128::attn_pipe128_kernel;
     static unsigned long long lds_done = 0;
-    if (const int rc = reserve_lds((const void*)kern, pipe128::SMEM, &lds_done, "ltxmi_attention_fwd_bf16")) return rc;
+    if (const int rc = reserve_lds((const void*)kern, pipe128::SMEM + 16, &lds_done, "ltxmi_attention_fwd_bf16")) return rc;
     p.q_tiles = (p.Lq + pipe128::Q_PER_WG - 1) / pipe128::Q_PER_WG;
     const int64_t grid = (int64_t)p.B * p.H * p.q_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pipe128::SMEM, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pipe128::SMEM + 16, stream, p);
     return check_launch("ltxmi_attention_fwd_bf16");
 }
 

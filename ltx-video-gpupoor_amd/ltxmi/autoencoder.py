@@ -636,28 +636,32 @@ class CausalVideoAutoencoder(nn.Module):
         mu, lv = mv
         return mu if lv is None else torch.cat([mu, lv], dim=1)
 
+    def _hw_tile_grid(self, fn, x, tile, stride, blend_extent, keep):
+        """The spatial tiling shared by the tiled encode and decode (vae.py:156-191, 223-263): ``fn`` is applied to
+        ``tile`` x ``tile`` windows of the last two axes taken every ``stride`` positions; each result is cross-faded over
+        ``blend_extent`` with its upper and left neighbour (blend_v / blend_h, in this order), cropped to ``keep`` and the
+        crops are stitched back together."""
+        H, W = x.shape[3], x.shape[4]
+        grid = [[fn(x[:, :, :, top:top + tile, left:left + tile]) for left in range(0, W, stride)]
+                for top in range(0, H, stride)]
+        bands = []
+        for r, row in enumerate(grid):
+            done = []
+            for c, t in enumerate(row):
+                if r:
+                    t = self._blend(grid[r - 1][c], t, blend_extent, 3)
+                if c:
+                    t = self._blend(row[c - 1], t, blend_extent, 4)
+                row[c] = t                       # (the right / lower neighbours blend against the blended tile, as there)
+                done.append(t[:, :, :, :keep, :keep])
+            bands.append(torch.cat(done, dim=4))
+        return torch.cat(bands, dim=3)
+
     def _hw_tiled_encode(self, x):                                               # vae.py:156-191
-        overlap_size = int(self.tile_sample_min_size * (1 - self.tile_overlap_factor))
         blend_extent = int(self.tile_latent_min_size * self.tile_overlap_factor)
-        row_limit = self.tile_latent_min_size - blend_extent
-        rows = []
-        for i in range(0, x.shape[3], overlap_size):
-            row = []
-            for j in range(0, x.shape[4], overlap_size):
-                tile = x[:, :, :, i:i + self.tile_sample_min_size, j:j + self.tile_sample_min_size]
-                row.append(self._cat_moments(self._encode(tile)))
-            rows.append(row)
-        result_rows = []
-        for i, row in enumerate(rows):
-            result_row = []
-            for j, tile in enumerate(row):
-                if i > 0:
-                    tile = self._blend(rows[i - 1][j], tile, blend_extent, 3)
-                if j > 0:
-                    tile = self._blend(row[j - 1], tile, blend_extent, 4)
-                result_row.append(tile[:, :, :, :row_limit, :row_limit])
-            result_rows.append(torch.cat(result_row, dim=4))
-        return torch.cat(result_rows, dim=3)
+        return self._hw_tile_grid(lambda t: self._cat_moments(self._encode(t)), x, self.tile_sample_min_size,
+                                  int(self.tile_sample_min_size * (1 - self.tile_overlap_factor)), blend_extent,
+                                  self.tile_latent_min_size - blend_extent)
 
     def encode(self, z, return_dict: bool = True, _stats=None):
         """vae.py:265-312: pixels [B,3,F,H,W] -> AutoencoderKLOutput(latent_dist).  ``_stats`` (std, mean)
@@ -716,27 +720,10 @@ class CausalVideoAutoencoder(nn.Module):
         return ops.tile_blend_(a.contiguous(), b, extent, dim)
 
     def _hw_tiled_decode(self, z, target_shape, timestep=None, stats=None):      # vae.py:223-263
-        overlap_size = int(self.tile_latent_min_size * (1 - self.tile_overlap_factor))
         blend_extent = int(self.tile_sample_min_size * self.tile_overlap_factor)
-        row_limit = self.tile_sample_min_size - blend_extent
-        rows = []
-        for i in range(0, z.shape[3], overlap_size):
-            row = []
-            for j in range(0, z.shape[4], overlap_size):
-                tile = z[:, :, :, i:i + self.tile_latent_min_size, j:j + self.tile_latent_min_size]
-                row.append(self._decode(tile, target_shape=target_shape, timestep=timestep, stats=stats))
-            rows.append(row)
-        result_rows = []
-        for i, row in enumerate(rows):
-            result_row = []
-            for j, tile in enumerate(row):
-                if i > 0:
-                    tile = self._blend(rows[i - 1][j], tile, blend_extent, 3)
-                if j > 0:
-                    tile = self._blend(row[j - 1], tile, blend_extent, 4)
-                result_row.append(tile[:, :, :, :row_limit, :row_limit])
-            result_rows.append(torch.cat(result_row, dim=4))
-        return torch.cat(result_rows, dim=3)
+        return self._hw_tile_grid(lambda t: self._decode(t, target_shape=target_shape, timestep=timestep, stats=stats), z,
+                                  self.tile_latent_min_size, int(self.tile_latent_min_size * (1 - self.tile_overlap_factor)),
+                                  blend_extent, self.tile_sample_min_size - blend_extent)
 
     def _hw_tiled_extent(self, n_latent):
         """Pixels ``_hw_tiled_decode`` returns along an axis of ``n_latent`` latent positions (every tile cropped to

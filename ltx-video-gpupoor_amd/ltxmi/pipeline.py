@@ -79,20 +79,18 @@ class LTXVideoPipeline:
         x_start, y_start = item.media_x, item.media_y
         x_start = (width - w) // 2 if x_start is None else x_start
         y_start = (height - h) // 2 if y_start is None else y_start
-        x_end, y_end = x_start + w, y_start + h
-        assert x_end <= width and y_end <= height, \
-            f"Conditioning item {x_start}:{x_end}x{y_start}:{y_end} is out of bounds for target size {width}x{height}"
+        if x_start + w > width or y_start + h > height:
+            raise AssertionError(f"Conditioning item {x_start}:{x_start + w}x{y_start}:{y_start + h} is out of bounds for "
+                                 f"target size {width}x{height}")
         if strip_latent_border:
-            if x_start > 0:
-                x_start += scale
-                latents = latents[:, :, :, :, 1:]
-            if y_start > 0:
-                y_start += scale
-                latents = latents[:, :, :, 1:, :]
-            if x_end < width:
-                latents = latents[:, :, :, :, :-1]
-            if y_end < height:
-                latents = latents[:, :, :, :-1, :]
+            # one latent row / column is dropped on every side of the item that does not touch the frame's border
+            # (pipeline_ltx_video.py:1598-1611); a cut on the left / top moves the item's origin by one latent
+            cut_l, cut_t = int(x_start > 0), int(y_start > 0)
+            cut_r, cut_b = int(x_start + w < width), int(y_start + h < height)
+            hl, wl = latents.shape[-2], latents.shape[-1]
+            latents = latents[..., cut_t:hl - cut_b, cut_l:wl - cut_r]
+            x_start += cut_l * scale
+            y_start += cut_t * scale
         return latents, x_start // scale, y_start // scale
 
     @staticmethod

@@ -183,6 +183,29 @@ def test_attention_pipelined_kernel_edges(Lq, Lk, spike):
     check(out, attn_truth(q, k, v), what=f"pipelined attention Lq{Lq} Lk{Lk}")
 
 
+@pytest.mark.parametrize("Lq,Lk,spike", [(256, 1024, "none"), (300, 1029, "late"), (256, 1100, "redo"), (512, 1500, "redo")])
+def test_attention_pipelined_kernel_head_dim_128(Lq, Lk, spike):
+    """The head_dim-128 pipelined kernel (attention_pipe128.hip: >= 128 query tiles of 256 rows, >= 1024 keys).  Its
+    first two key tiles run the exact online softmax (rescale whenever a row maximum grows); from then on every row keeps
+    its reference ("steady" form, no rescale in the loop) and a workgroup in which a score outgrows its reference by more
+    than 100 bits redoes its item in the exact form.  Cases: settled maxima; a maximum that jumps late but stays within the
+    steady form's range (P > 1 against the old reference: rule 26, the branch that is wrong whenever taken needs its own
+    test); and scores 400+ bits above everything before them in the LAST tile / in the middle -> the redo path, for block A
+    and block B rows."""
+    from ltxmi import ops
+    B, H, dh = 4, 32, 128
+    assert ops.attention_kernel_id(B, H, Lq, Lk, dh, False, H * dh, H * dh) == 6
+    q, k, v = rnd(B, Lq, H, dh, seed=43), rnd(B, Lk, H, dh, seed=44), rnd(B, Lk, H, dh, seed=45)
+    if spike == "late":
+        k[:, Lk - 30] = q[:, 5] * 1.5           # ~ +17 nats in the last tile: block A rows of wave 0
+        k[:, Lk // 2] = q[:, 40] * 1.2          # block B
+    if spike == "redo":
+        k[:, Lk - 30] = q[:, 5] * 30.0          # q.k c ~ 30 * 128 / sqrt(128) = 340 nats above the rest
+        k[:, Lk // 2] = q[:, 40] * 25.0
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    check(out, attn_truth(q, k, v), what=f"head_dim-128 pipelined attention Lq{Lq} Lk{Lk} spike={spike}")
+
+
 def test_pay_attention_seam_contract():
     from ltxmi import pay_attention
     B, L, H, dh = 2, 130, 2, 64

@@ -245,6 +245,29 @@ def test_transformer_2b_one_block_full_size():
     assert_parity(out, truth, eager, "2B-width, 1 block, N 4992, B_eff 3")
 
 
+def test_transformer_13b_width_one_block():
+    """The widths of the model the reference actually ships (LTXV is hard-wired to the 13B 0.9.7 checkpoint, ltxv.py:171-194):
+    D = 4096 = 32 heads x 128, FF = 4 D = 16384, caption 4096 -- assumed from the published 13B architecture; the real
+    config lives in the checkpoint's metadata, which the repo does not hold -- through ONE BasicTransformerBlock plus the
+    embeddings and the output head.  N = 1040 tokens x B_eff 2 puts self-attention on the head_dim-128 pipelined kernel
+    (2 x 32 x 5 = 320 workgroups, 1040 keys) with q's norm + RoPE applied on load over 64 partial sums per row."""
+    import ltxmi
+    from ltxmi import ops
+    from oracle import dit
+    grid, B, T = (5, 13, 16), 2, 128
+    cfg, sd32, x, enc, mask, ts, frac = dit_case(32, 128, 1, grid, B, T, caption=4096, seed=26)
+    assert cfg["num_attention_heads"] * cfg["attention_head_dim"] == 4096
+    assert ops.attention_kernel_id(B, 32, 1040, 1040, 128) == 6
+    truth, eager = run_oracles(cfg, sd32, x, enc, mask, ts, frac, grid)
+    m = build_model(cfg, sd32)
+    assert m.transformer_blocks[0].ff.net[2].weight.shape == (4096, 16384)
+    fc = m.precompute_freqs_cis(frac.to(DEV))
+    out = m(x.to(DEV), freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV),
+            timestep=ts.to(DEV), latent_shape=grid, ltxv_model=_Holder(), return_dict=False)[0]
+    assert out.shape == (2, 1040, 128)
+    assert_parity(out, truth, eager, "13B width (D 4096, 32 x 128), 1 block, N 1040")
+
+
 def test_transformer_2b_full_depth():
     """The whole 2B model: all 28 layers at the real widths (D 2048, 32 x 64 heads, FF 8192, caption 4096, T 256), B_eff 3
     with the STG row perturbed from block 19 (the 2B default), on an eighth-size token grid (N = 624) so that the two CPU

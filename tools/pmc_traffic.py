@@ -3,7 +3,7 @@
 prescribes) into per-launch HBM traffic per kernel.  gfx950 corrections (MI355X_MICROARCH.md, HBM):
 FETCH_SIZE is reported in KiB and counts 64 B per 128-B request on wide coalesced reads -> x2;
 WRITE_SIZE in KiB is exact for streaming stores.
-Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <out.md> [name of the committed .md]"""
+Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <out.md> [name of the committed .md] [profiled command]"""
 import csv
 import json
 import re
@@ -50,12 +50,18 @@ def main():
     att = [r for r in rows if "attn_pipe_kernel" in r["kernel"]]
     if att:
         out["attention_hbm_bytes_per_launch"] = max(att, key=lambda r: r["launches"])["hbm_bytes_per_launch"]
+    # the VAE legs' roofline kernel: the direct convolution with the plain store and the largest grid (128 -> 128 at the
+    # full-resolution stage)
+    cv = [r for r in rows if "conv3d_direct_kernel<0>" in r["kernel"]]
+    if cv:
+        out["conv_direct_hbm_bytes_per_launch"] = max(cv, key=lambda r: int(r["grid"] or 0))["hbm_bytes_per_launch"]
     out["source"] = sys.argv[5] if len(sys.argv) > 5 else sys.argv[4]
+    what = sys.argv[6] if len(sys.argv) > 6 else "python bench.py --steps 1 --warmup 1 --no-extras"
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     with open(sys.argv[4], "w") as f:
         f.write("# HBM traffic per launch from PMC counters\n\n"
                 "`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes over "
-                "`python bench.py --steps 1 --warmup 1 --no-extras`; FETCH_SIZE x2 (gfx950 counts 64 B per "
+                f"`{what}`; FETCH_SIZE x2 (gfx950 counts 64 B per "
                 "128-B request), both KiB -> bytes.\n\n| kernel | grid | launches | fetch MB | write MB | total MB |\n|---|---|---|---|---|---|\n")
         for r in rows[:40]:
             f.write(f"| `{r['kernel']}` | {r['grid']} | {r['launches']} | {r['fetch_bytes_per_launch'] / 1e6:.1f} | "

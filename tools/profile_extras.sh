@@ -19,5 +19,11 @@ echo "vae stats done"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
     --output-format csv -d "$OUT/vaepmc" -o vaepmc -- python3 "$ROOT/tools/vae_time.py" 2 > "$OUT/vaepmc.log" 2>&1
 python3 "$ROOT/tools/pmc_mfma.py" "$(find "$OUT/vaepmc" -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_vae.md"
-rm -rf "$OUT/attn" "$OUT/vae" "$OUT/vaepmc"
+# HBM-side traffic of a VAE decode (the convolution against BOTH roofs): FETCH_SIZE / WRITE_SIZE in passes of their own
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/vaefetch" -o vaefetch -- python3 "$ROOT/tools/vae_time.py" 2 > "$OUT/vaefetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/vaewrite" -o vaewrite -- python3 "$ROOT/tools/vae_time.py" 2 > "$OUT/vaewrite.log" 2>&1
+python3 "$ROOT/tools/pmc_traffic.py" "$(find "$OUT/vaefetch" -name '*counter_collection.csv' | head -1)" \
+    "$(find "$OUT/vaewrite" -name '*counter_collection.csv' | head -1)" "$OUT/traffic_vae.json" "$OUT/${TAG}_pmc_traffic_vae.md" "profiles/${TAG}_pmc_traffic_vae.md" "python tools/vae_time.py 2 (VAE decode 768x512x97)"
+echo "vae traffic done"
+rm -rf "$OUT/attn" "$OUT/vae" "$OUT/vaepmc" "$OUT/vaefetch" "$OUT/vaewrite"
 ls -la "$OUT"

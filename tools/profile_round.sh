@@ -18,7 +18,7 @@ echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- $CMD > "$OUT/write.log" 2>&1
 echo "write done"
 python3 "$OLDPWD/tools/pmc_traffic.py" "$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)" \
-    "$(find "$OUT/write" -name '*counter_collection.csv' | head -1)" "$OUT/traffic.json" "$OUT/${TAG}_pmc_traffic.md" "profiles/${TAG}_pmc_traffic.md"
+    "$(find "$OUT/write" -name '*counter_collection.csv' | head -1)" "$OUT/traffic.json" "$OUT/${TAG}_pmc_traffic.md" "profiles/${TAG}_pmc_traffic.md" "python bench.py --steps 2 --warmup 1 --no-extras"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE \
     --output-format csv -d "$OUT/mfma" -o mfma -- $CMD > "$OUT/mfma.log" 2>&1
 python3 "$OLDPWD/tools/pmc_mfma.py" "$(find "$OUT/mfma" -name '*counter_collection.csv' | head -1)" "$OUT/${TAG}_pmc_mfma.md"
