@@ -52,7 +52,7 @@ constexpr int KV_TILE = 64;
 constexpr int ROW_BYTES = DH * 2;
 constexpr int TILE_BYTES = KV_TILE * DH * 2;     // 8 KiB: one K or V tile
 constexpr int RING = 4;
-constexpr int SMEM = 2 * RING * TILE_BYTES;      // K ring | V ring = 64 KiB
+constexpr int SMEM = 2 * RING * TILE_BYTES;      // K ring | V ring = 64 KiB (+ 16 B behind them: the redo flag)
 constexpr int Q_PER_WG = 256;                    // 4 waves x 2 blocks x 32 rows
 
 struct Blk {
@@ -76,7 +76,8 @@ struct Lane {
 // scores against the K slot `ks`.
 // hook(j) runs once per chunk j, right behind the chunk's MFMA: the kernel uses it to issue its LDS-DMA pieces one at a
 // time in the shadow of an MFMA instead of as a burst of four behind the barrier
-template <bool TAIL, typename Hook>
+// STEADY: X's reference maximum is final (see the kernel): no tile maximum, no rescale.
+template <bool STEADY, typename Hook>
 __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const char* vs, const Lane& L,
                                         const bf16x8& ones, float c, int key0, int Lk, Stamps& st, int st0, Hook&& hook) {
     // ---- head: K fragments of the whole slot (8 x ds_read_b128), Y's row sums, X's row max
@@ -87,7 +88,8 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp) Y.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Y.pf[sp]), Y.l, 0, 0, 0);
 
-    if (TAIL) {
+    if (key0 + KV_TILE > Lk) {
+        asm volatile("; ragged key tile (a wave-uniform branch, not a template instance)" ::: "memory");
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -96,34 +98,35 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
                 if (key >= Lk) X.s[kb][e] = -INFINITY;
             }
     }
-    float mt;
-    {
-        auto max3 = [](float a, float b, float c3) { return fmaxf(fmaxf(a, b), c3); };
-        float l1[11];
+    if (!STEADY) {
+        float mt;
+        {
+            auto max3 = [](float a, float b, float c3) { return fmaxf(fmaxf(a, b), c3); };
+            float l1[11];
 #pragma unroll
-        for (int g = 0; g < 5; ++g) {
-            l1[g] = max3(X.s[0][3 * g], X.s[0][3 * g + 1], X.s[0][3 * g + 2]);
-            l1[5 + g] = max3(X.s[1][3 * g], X.s[1][3 * g + 1], X.s[1][3 * g + 2]);
+            for (int g = 0; g < 5; ++g) {
+                l1[g] = max3(X.s[0][3 * g], X.s[0][3 * g + 1], X.s[0][3 * g + 2]);
+                l1[5 + g] = max3(X.s[1][3 * g], X.s[1][3 * g + 1], X.s[1][3 * g + 2]);
+            }
+            l1[10] = max3(X.s[0][15], X.s[1][15], l1[0]);
+            const float a = max3(l1[1], l1[2], l1[3]), b2 = max3(l1[4], l1[5], l1[6]), c2 = max3(l1[7], l1[8], l1[9]);
+            mt = fmaxf(max3(a, b2, c2), l1[10]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        l1[10] = max3(X.s[0][15], X.s[1][15], l1[0]);
-        const float a = max3(l1[1], l1[2], l1[3]), b2 = max3(l1[4], l1[5], l1[6]), c2 = max3(l1[7], l1[8], l1[9]);
-        mt = fmaxf(max3(a, b2, c2), l1[10]);
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-        mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    const float m_new = fmaxf(X.m, mt);
-    // the O-wide rescale is a real, rarely taken wave-uniform branch (the running max settles after
-    // the first few tiles)
-    if (__any(m_new != X.m)) {
-        asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
-        const float alpha = fast_exp2((X.m - m_new) * c);
-        X.l[0] *= alpha;
-        X.l[1] *= __shfl(alpha, (L.lane + 16) & 63, 64);
+        const float m_new = fmaxf(X.m, mt);
+        // the O-wide rescale is a real wave-uniform branch
+        if (__any(m_new != X.m)) {
+            asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
+            const float alpha = fast_exp2((X.m - m_new) * c);
+            X.l[0] *= alpha;
+            X.l[1] *= __shfl(alpha, (L.lane + 16) & 63, 64);
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) X.o[d][e] *= alpha;
-        X.m = m_new;
+                for (int e = 0; e < 16; ++e) X.o[d][e] *= alpha;
+            X.m = m_new;
+        }
     }
     const float nmoff = -X.m * c;
     __builtin_amdgcn_sched_barrier(0);
@@ -276,8 +279,6 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     };
 
     const int nt = (p.Lk + KV_TILE - 1) / KV_TILE;
-    const int n_full = p.Lk / KV_TILE;
-    dma_k(0); dma_v(0); dma_k(1); dma_v(1); dma_k(2);
 
     // ---- per-lane LDS read offsets (attention.hip's images)
     L.k_rd[0] = L.r * ROW_BYTES;
@@ -338,6 +339,22 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { X.o[d][e] = 0.f; X.s[d][e] = 0.f; }
     };
+    // The loop exists in two forms.  EXACT: the textbook online softmax -- tile maximum, running maximum, rescale of O / l
+    // whenever a row's maximum grows.  STEADY: every row keeps the reference it has (P = 2^((s - m) c) may exceed 1, which
+    // floating point does not mind) -- no tile maximum (14 VALU instructions per block and tile on a loop that is
+    // VALU-issue-bound), no branch.  The first two key tiles run EXACT, while the maxima are still settling; the rest run
+    // STEADY.  A score ~100 bits (69 nats) or more above everything in its row's first 128 keys would overflow against the
+    // fixed reference (or make 1 / l denormal): that leaves a row sum or accumulator of magnitude >= 2^100, which the
+    // workgroup checks for after its last key tile -- and then redoes the item with EXACT throughout (attempt 1).
+    volatile int* redo_flag = (volatile int*)(smem + SMEM);           // one word behind the rings
+    if (tid == 0) *redo_flag = 0;
+    const bool wave_idle = qt * Q_PER_WG + wave * 64 >= p.Lq;
+    Stamps st;
+#ifdef LTXMI_ATTN_STAMPS
+    unsigned long long rt0_ = 0;
+#endif
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    dma_k(0); dma_v(0); dma_k(1); dma_v(1); dma_k(2);
     init(A, 0);
     init(Bk, 1);
     {
@@ -354,14 +371,12 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     // A wave whose 64 query rows all lie past Lq (the half-empty last query tile of a (batch, head): N = 4992 = 19.5 x 256)
     // keeps the workgroup's K/V stream going -- its LDS-DMA pieces, the barriers, the counted waits -- and computes nothing,
     // so its SIMD partner (a wave of the other resident workgroup) gets the pipes to itself.
-    Stamps st;
 #ifdef LTXMI_ATTN_STAMPS
     for (int i = 0; i < 8; ++i) st.acc[i] = 0;
     { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory"); st.prev = t0_; }
-    unsigned long long rt0_;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0_)::"memory");
 #endif
-    const bool wave_idle = qt * Q_PER_WG + wave * 64 >= p.Lq;
+    const int t_exact = attempt == 0 ? (nt < 2 ? nt : 2) : nt;
     if (wave_idle) {
         for (int t = 0; t < nt; ++t) {
             __builtin_amdgcn_s_barrier();
@@ -380,10 +395,10 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
             }
 
         const float c = p.scale_log2e;
-        using no_tail = std::integral_constant<bool, false>;
-        using with_tail = std::integral_constant<bool, true>;
-        auto iteration = [&](int t, auto tail_tag) {
-            constexpr bool TAIL = decltype(tail_tag)::value;
+        using exact_form = std::integral_constant<bool, false>;
+        using steady_form = std::integral_constant<bool, true>;
+        auto iteration = [&](int t, auto steady_tag) {
+            constexpr bool STEADY = decltype(steady_tag)::value;
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             STAMP(0);
@@ -391,18 +406,18 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
             // this iteration's four LDS-DMA pieces -- K(t+3) into the slot K(t-1) left at this barrier, V(t+2) into V(t-2)'s --
             // go out one at a time behind an MFMA (chunks 3 and 11 of each segment), in this order (the counted wait below
             // relies on it): a burst of four behind the barrier cost ~200 cycles per iteration with the wave issuing nothing else
-            segment<TAIL>(A, Bk, kring + (t & 3) * TILE_BYTES, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2,
+            segment<STEADY>(A, Bk, kring + (t & 3) * TILE_BYTES, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2,
                           [&](int j) { if (j == 3) dma_k1(t + 3, 0); else if (j == 11) dma_k1(t + 3, 1); });
-            segment<TAIL>(Bk, A, kring + ((t + 1) & 3) * TILE_BYTES, vring + (t & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 4,
+            segment<STEADY>(Bk, A, kring + ((t + 1) & 3) * TILE_BYTES, vring + (t & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 4,
                           [&](int j) { if (j == 3) dma_v1(t + 2, 0); else if (j == 11) dma_v1(t + 2, 1); });
             // everything issued before this iteration's four pieces has landed: K(t+2), V(t+1)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             STAMP(6);
         };
-        for (int t = 0; t < n_full; ++t) iteration(t, no_tail{});
-        if (n_full < nt) iteration(n_full, with_tail{});
-
+        int t = 0;
+        for (; t < t_exact; ++t) iteration(t, exact_form{});
+        for (; t < nt; ++t) iteration(t, steady_form{});
     }
 
 #ifdef LTXMI_ATTN_STAMPS
@@ -431,11 +446,35 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
                 Bk.o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), __builtin_bit_cast(bf16x8, Bk.pf[sp]), Bk.o[d], 0, 0, 0);
             }
     }
-    // the out-of-range pieces of tiles >= nt are still landing (as zeros): drain them before the
-    // rings become the output scratch
+    // the out-of-range pieces of tiles >= nt are still landing (as zeros): drain them before the rings are reused (as the
+    // output scratch, or by the redo's stream); then agree on the redo
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    bool outgrown = false;
+    if (attempt == 0 && t_exact < nt && !wave_idle) {
+        // a row sum or an accumulator of magnitude >= 2^100 (or inf / NaN: the test is on the exponent bits, the file is
+        // built with -fno-honor-nans) = a score outgrew its row's fixed reference.  Not only overflow: 1 / l for l > 2^126 is
+        // a denormal and flushes to zero; a legitimate l is at most (keys) x 2^(a few bits).
+        constexpr uint32_t OUTGROWN_EXP = (127u + 100u) << 23;
+        uint32_t worst = 0;
+        auto scan = [&](const Blk& X) {
+            worst |= (uint32_t)((__float_as_uint(X.l[0]) & 0x7f800000u) >= OUTGROWN_EXP);
+            worst |= (uint32_t)((__float_as_uint(X.l[1]) & 0x7f800000u) >= OUTGROWN_EXP);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) worst |= (uint32_t)((__float_as_uint(X.o[d][e]) & 0x7f800000u) >= OUTGROWN_EXP);
+        };
+        scan(A);
+        scan(Bk);
+        outgrown = __any(worst != 0);
+    }
+    if (outgrown && L.lane == 0) *redo_flag = 1;
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    const int redo = *redo_flag;
+    __builtin_amdgcn_s_barrier();
+    if (attempt == 1 || redo == 0) break;
+    }
 
     // ---- epilogue: O = O^T / l, through a per-wave LDS scratch so that rows leave whole (attention.hip)
     auto store = [&](Blk& X, int blk) {
@@ -491,10 +530,10 @@ int launch_attn_pipe(AttnParams p, hipStream_t stream) {
     if (!attn_pipe_span_ok(p.Lk, p.k_sl, p.v_sl, pipe::DH)) return -1;
     auto kern = pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC>;
     static unsigned long long lds_done = 0;
-    if (const int rc = reserve_lds((const void*)kern, pipe::SMEM, &lds_done, "ltxmi_attention_fwd_bf16")) return rc;
+    if (const int rc = reserve_lds((const void*)kern, pipe::SMEM + 16, &lds_done, "ltxmi_attention_fwd_bf16")) return rc;
     p.q_tiles = (p.Lq + pipe::Q_PER_WG - 1) / pipe::Q_PER_WG;
     const int64_t grid = (int64_t)p.B * p.H * p.q_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pipe::SMEM, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pipe::SMEM + 16, stream, p);
     return check_launch("ltxmi_attention_fwd_bf16");
 }
 

@@ -86,9 +86,10 @@ __device__ __forceinline__ bf16x8 vread(const char* slot, const Lane& L, int i) 
 // executed -- makes hipcc route one block's 64 accumulators through VGPRs on the hot path (64 v_accvgpr_write per key tile).
 // So the loop exists twice: the EXACT form (rescale whenever a row maximum grows) runs the first two key tiles, where the
 // maxima are still settling; the STEADY form then keeps each row's reference fixed -- P = 2^((s - m) c) may exceed 1, which
-// costs nothing in fp32 / bf16 floating point as long as it cannot overflow -- and contains no rescale at all, only a check
-// that no score has outgrown its reference by more than 2^STEADY_MAX_LOG2.  A workgroup in which that ever happens (scores
-// jumping by > 69 nats after the first 128 keys) redoes its item with the exact form throughout.
+// costs nothing in fp32 / bf16 floating point as long as it cannot overflow -- and contains no rescale and no row maximum
+// at all.  A score ~100 bits (69 nats) or more above everything in the row's first 128 keys leaves a row sum or an
+// accumulator of magnitude >= 2^100 (up to non-finite); a workgroup that finds one after its last key tile redoes its item
+// with the exact form throughout.
 __device__ __forceinline__ void mfma_s0(f32x16& acc, const bf16x8& k, const bf16x8& q) {      // acc = K Q^T (first k-step)
     asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(k), "a"(q));
 }
@@ -105,8 +106,6 @@ __device__ __forceinline__ void settle_o(f32x16 (&o)[N]) {
     static_assert(N == 4, "four O^T blocks");
     asm volatile("s_nop 15\n\ts_nop 7" : "+a"(o[0]), "+a"(o[1]), "+a"(o[2]), "+a"(o[3]));
 }
-constexpr float STEADY_MAX_LOG2 = 100.0f;        // a score may exceed its row's reference by this many bits before the redo
-
 // One segment: VALU = softmax of X's pending scores (X.s -> X.pf, X.m, rescale of X.o / X.l) and the running maximum of the
 // scores Y produces; matrix pipe = Y's next scores (kq: fragments 0..3 of this segment's K slot, read during the previous
 // segment; the rest from ks_cur), PV with Y's pending P against the V slot vs, and the row sums of the P fragments as they
@@ -114,7 +113,7 @@ constexpr float STEADY_MAX_LOG2 = 100.0f;        // a score may exceed its row's
 // ragged tile is masked where its scores are produced (a wave-uniform branch).  hook(j): the kernel's LDS-DMA issue points.
 template <bool EXACT, typename Hook>
 __device__ __forceinline__ void segment(Blk& X, Blk& Y, bf16x8 (&kq)[4], const char* ks_cur, const char* ks_next, const char* vs,
-                                        const Lane& L, const bf16x8& ones, float c, int key0_y, int Lk, bool& outgrown, Hook&& hook) {
+                                        const Lane& L, const bf16x8& ones, float c, int key0_y, int Lk, Hook&& hook) {
     if (EXACT) {
         const float m_new = fmaxf(X.m, X.mt);
         // the O-wide rescale: a real wave-uniform branch
@@ -130,10 +129,9 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, bf16x8 (&kq)[4], const c
                 for (int e = 0; e < 16; ++e) X.o[d][e] *= alpha;
             X.m = m_new;
         }
-    } else {
-        // steady form: the reference stays; only watch for a score that would overflow against it
-        outgrown = outgrown || __any((X.mt - X.m) * c > STEADY_MAX_LOG2);
     }
+    // (steady form: the reference stays, nothing to do here -- and no tile maximum is computed at all: an overflow against
+    // the fixed reference shows as a non-finite row sum / output at the end of the item)
     const float nmoff = -X.m * c;
     __builtin_amdgcn_sched_barrier(0);
 
@@ -192,13 +190,15 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, bf16x8 (&kq)[4], const c
                     if (key >= Lk) Y.s[kbm][e] = -INFINITY;
                 }
             }
-            mt = fmaxf(fmaxf(mt, Y.s[kbm][em]), Y.s[kbm][em + 1]);
-            asm volatile("" : "+v"(mt));            // (pinned to this chunk, like the conversions)
+            if (EXACT) {
+                mt = fmaxf(fmaxf(mt, Y.s[kbm][em]), Y.s[kbm][em + 1]);
+                asm volatile("" : "+v"(mt));        // (pinned to this chunk, like the conversions)
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     X.pf[3][3] = pack_bf16(pa, pb);
-    {
+    if (EXACT) {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
         Y.mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
@@ -348,7 +348,6 @@ __global__ __launch_bounds__(256, 1) void attn_pipe128_kernel(AttnParams p) {
     const float c = p.scale_log2e;
     volatile int* redo_flag = (volatile int*)(smem + SMEM);         // one word behind the rings
     if (tid == 0) *redo_flag = 0;
-    bool outgrown = false;
     // attempt 0: exact form for the first two key tiles, steady form for the rest; attempt 1 (only if some wave of the
     // workgroup saw a score outgrow its reference): the whole item again in the exact form
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -408,9 +407,9 @@ __global__ __launch_bounds__(256, 1) void attn_pipe128_kernel(AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
             const char* k_t = kring + (t & 3) * TILE_BYTES;
             const char* k_t1 = kring + ((t + 1) & 3) * TILE_BYTES;
-            segment<EXACT>(A, Bk, kq, k_t, k_t1, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, outgrown,
+            segment<EXACT>(A, Bk, kq, k_t, k_t1, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk,
                            [&](int j) { if ((j & 7) == 3) dma_k1(t + 3, j >> 3); });
-            segment<EXACT>(Bk, A, kq, k_t1, k_t1, vring + (t & 3) * TILE_BYTES, L, ones, c, (t + 1) * KV_TILE, p.Lk, outgrown,
+            segment<EXACT>(Bk, A, kq, k_t1, k_t1, vring + (t & 3) * TILE_BYTES, L, ones, c, (t + 1) * KV_TILE, p.Lk,
                            [&](int j) { if ((j & 7) == 3) dma_v1(t + 2, j >> 3); });
             // everything issued before this iteration's eight pieces has landed: K(t+2), V(t+1)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -431,13 +430,33 @@ __global__ __launch_bounds__(256, 1) void attn_pipe128_kernel(AttnParams p) {
         // the out-of-range pieces of tiles >= nt are still landing (as zeros): drain them before the rings are reused (as
         // the output scratch, or by the redo's stream); and agree on the redo
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        bool outgrown = false;
+        if (attempt == 0 && t_exact < nt) {
+            // did a score outgrow its row's fixed reference?  Then a row sum or an accumulator has magnitude >= 2^100 (or is
+            // inf / NaN: the test is on the exponent bits, the file is built with -fno-honor-nans).  Not only overflow:
+            // 1 / l for l > 2^126 is a denormal and flushes to zero; a legitimate l is at most (keys) x 2^(a few bits).
+            constexpr uint32_t OUTGROWN_EXP = (127u + 100u) << 23;
+            settle_o(A.o);
+            settle_o(Bk.o);
+            uint32_t worst = 0;
+            auto scan = [&](const Blk& X) {
+                worst |= (uint32_t)((__float_as_uint(X.l[0]) & 0x7f800000u) >= OUTGROWN_EXP);
+                worst |= (uint32_t)((__float_as_uint(X.l[1]) & 0x7f800000u) >= OUTGROWN_EXP);
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) worst |= (uint32_t)((__float_as_uint(X.o[d][e]) & 0x7f800000u) >= OUTGROWN_EXP);
+            };
+            scan(A);
+            scan(Bk);
+            outgrown = __any(worst != 0);
+        }
         if (outgrown && L.lane == 0) *redo_flag = 1;
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const int redo = *redo_flag;
         __builtin_amdgcn_s_barrier();
         if (attempt == 1 || redo == 0) break;
-        outgrown = false;
     }
 
 

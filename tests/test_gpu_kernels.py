@@ -183,6 +183,28 @@ def test_attention_pipelined_kernel_edges(Lq, Lk, spike):
     check(out, attn_truth(q, k, v), what=f"pipelined attention Lq{Lq} Lk{Lk}")
 
 
+@pytest.mark.parametrize("Lq,Lk,spike", [(256, 1, False), (256, 200, False), (512, 448, "redo"), (256, 1029, "redo"), (300, 1029, "late")])
+def test_attention_pipelined_kernel_steady_form_and_redo(Lq, Lk, spike):
+    """The head_dim-64 pipelined kernel runs its first two key tiles with the exact online softmax and the rest in the
+    "steady" form (fixed row references, no tile maximum, no rescale); a workgroup whose row sums / accumulators reach
+    2^100 afterwards redoes its item in the exact form.  Cases: fewer key tiles than the exact prefix; a late maximum
+    within the steady form's range (P > 1 against the old reference); scores 100+ bits above their row's first 128 keys in
+    the last tile and in the middle (rows of block A and block B) -> the redo path, incl. rows whose row sum stays finite
+    but would make 1 / l denormal (+126 .. +128 bits)."""
+    from ltxmi import ops
+    B, H, dh = 8, 64 if Lq <= 256 else 32, 64
+    assert ops.attention_kernel_id(B, H, Lq, Lk, dh, False, H * dh, H * dh) == 3
+    q, k, v = rnd(B, Lq, H, dh, seed=46), rnd(B, Lk, H, dh, seed=47), rnd(B, Lk, H, dh, seed=48)
+    if spike == "late":
+        k[:, Lk - 30] = q[:, 5] * 2.0           # ~ +16 nats in the last tile
+        k[:, Lk // 2] = q[:, 40] * 1.5
+    if spike == "redo":
+        k[:, Lk - 30] = q[:, 5] * 40.0          # q.k c ~ 40 * 64 / 8 = 320 nats
+        k[:, Lk // 2] = q[:, 40] * 11.0         # ~ +88 nats = 127 bits: around the denormal-reciprocal edge for its row
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    check(out, attn_truth(q, k, v), what=f"pipelined attention (steady form) Lq{Lq} Lk{Lk} spike={spike}")
+
+
 @pytest.mark.parametrize("Lq,Lk,spike", [(256, 1024, "none"), (300, 1029, "late"), (256, 1100, "redo"), (512, 1500, "redo")])
 def test_attention_pipelined_kernel_head_dim_128(Lq, Lk, spike):
     """The head_dim-128 pipelined kernel (attention_pipe128.hip: >= 128 query tiles of 256 rows, >= 1024 keys).  Its
