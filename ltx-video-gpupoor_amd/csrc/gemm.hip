@@ -696,14 +696,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     // (akb = byte offset of k-tile kts inside a row of A: the caller computes it, and chooses the descriptors, BEFORE
     // phase A -- with one wave per SIMD every scalar instruction between the barrier and the first MFMA of phase B is
     // matrix-pipe idle time)
-    auto phase_b_rows = [&](int cur, rsrc_t ta, rsrc_t tw, int kts, int akb, bool do_stage, auto f0_tag) __attribute__((always_inline)) {
+    auto phase_b_rows = [&](int cur, rsrc_t ta, rsrc_t tw, int kts, int akb, auto dma_tag, auto f0_tag) __attribute__((always_inline)) {
         constexpr bool READ_F0 = decltype(f0_tag)::value;
+        constexpr bool DMA = decltype(dma_tag)::value;
         constexpr int NP = PPW;
         const char* sn = smem + (cur ^ 1) * STAGE_BYTES;
 #pragma unroll
         for (int g = 0; g < MI; ++g) {
-            if (do_stage && dma_wave) {
-                // row g's share: pieces [g NP / MI, (g + 1) NP / MI)
+            if (DMA) {
+                // row g's share: pieces [g NP / MI, (g + 1) NP / MI).  Issued unconditionally: when there is nothing left
+                // to stage (the last tile's last two K-tiles) the descriptors are empty and the pieces arrive as zeros in a
+                // stage nobody reads -- no branch inside the K loop, and a constant count for the counted waits.
 #pragma unroll
                 for (int q = (g * NP) / MI; q < ((g + 1) * NP) / MI; ++q) piece(cur, ta, tw, kts, akb, q);
             }
@@ -727,6 +730,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     using first_t = std::integral_constant<bool, true>;
     using next_t = std::integral_constant<bool, false>;
 
+    // The tile walk exists twice, once per role: the waves that issue the LDS-DMA (0 .. DMA_WAVES-1) and the waves that only
+    // compute.  With the role a run-time condition every MFMA row of phase B carried a wave-uniform branch (8 per K-tile).
+    const rsrc_t null_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+    auto walk = [&](auto dma_tag) __attribute__((always_inline)) {
+    using dma_t = decltype(dma_tag);
     int flat = 0;                            // running k-tile count: stage parity
     for (int ti = 0; ti < my_n; ++ti) {
         const bool has_next = ti + 1 < my_n;
@@ -734,6 +742,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             tile_origin(ti + 1, ns_m0, ns_n0);
             ns_a = rsrc_a(ns_m0);
             ns_w = rsrc_w(ns_n0);
+        } else {
+            ns_a = null_rsrc;                // nothing follows: what phase B still "stages" reads as zeros
+            ns_w = null_rsrc;
         }
         // What phase B of K-tile kt stages: k-tile (+2) of the (tile, k-tile) stream -- this tile's, or one of the next
         // tile's first two (its descriptors are scalars).  Chosen before phase A (see phase_b_rows).
@@ -742,7 +753,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
         const int kts = same_tile ? (KT) + 2 : (KT) + 2 - nk;                              \
         const rsrc_t st_a = same_tile ? cs_a : ns_a, st_w = same_tile ? cs_w : ns_w;      \
         const int akb = (int)(p.a_koff(kts) * 2);                                          \
-        const bool do_stage = same_tile || has_next;                                       \
         __builtin_amdgcn_sched_barrier(0);
         // ---- K-tile 0 (never the last: nk >= 2)
         {
@@ -758,7 +768,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             } else {
                 sync_all();
             }
-            phase_b_rows(cur, st_a, st_w, kts, akb, do_stage, std::integral_constant<bool, true>{});
+            phase_b_rows(cur, st_a, st_w, kts, akb, dma_t{}, std::integral_constant<bool, true>{});
             ++flat;
         }
         // ---- middle K-tiles
@@ -774,7 +784,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
 #endif
             sync_all();
             GSTAMP(2);
-            phase_b_rows(cur, st_a, st_w, kts, akb, do_stage, std::integral_constant<bool, true>{});
+            phase_b_rows(cur, st_a, st_w, kts, akb, dma_t{}, std::integral_constant<bool, true>{});
             GSTAMP(3);
 #ifdef LTXMI_GEMM_STAMPS
             gst_acc[5] += 1;
@@ -791,7 +801,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             sync_all();
             // next tile's K-tile 1 goes into the stage this K-tile just drained, piece by piece under the
             // MFMAs; all of it is issued BEFORE the stores, so vmcnt(N_STORES) at the next barrier covers it
-            phase_b_rows(cur, ns_a, ns_w, 1, akb1, has_next, std::integral_constant<bool, false>{});
+            phase_b_rows(cur, ns_a, ns_w, 1, akb1, dma_t{}, std::integral_constant<bool, false>{});
             GSTAMP(4);
             epilogue(cs_m0, cs_n0);
             GSTAMP(6);
@@ -808,6 +818,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             ++flat;
         }
     }
+    };
+    if (dma_wave) walk(std::integral_constant<bool, true>{});
+    else walk(std::integral_constant<bool, false>{});
 #ifdef LTXMI_GEMM_STAMPS
     if (g_gemm_stamps && lane == 0 && blockIdx.x < 256) {
         // [0] phase A, [1] vmcnt wait, [2] barrier, [3] phase B (middle K-tiles); [4] everything else in the K loops;
