@@ -178,13 +178,14 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
     STAMP(st0 + 1);
 }
 
-template <int OCC>
-__global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// One work item = one (batch, head, 256-row query tile).  REDO = false: the normal run (exact form for the first two key
+// tiles, steady form for the rest, then the check for outgrown references); returns true -- WITHOUT having stored anything --
+// when the workgroup has to go through the item again.  REDO = true: exact form throughout, always stores.
+template <bool REDO>
+__device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int tid, char* smem) {
     char* kring = smem;
     char* vring = smem + RING * TILE_BYTES;
 
-    const int tid = threadIdx.x;
     Lane L;
     L.lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -347,13 +348,12 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     // fixed reference (or make 1 / l denormal): that leaves a row sum or accumulator of magnitude >= 2^100, which the
     // workgroup checks for after its last key tile -- and then redoes the item with EXACT throughout (attempt 1).
     volatile int* redo_flag = (volatile int*)(smem + SMEM);           // one word behind the rings
-    if (tid == 0) *redo_flag = 0;
+    if (!REDO && tid == 0) *redo_flag = 0;
     const bool wave_idle = qt * Q_PER_WG + wave * 64 >= p.Lq;
     Stamps st;
 #ifdef LTXMI_ATTN_STAMPS
     unsigned long long rt0_ = 0;
 #endif
-    for (int attempt = 0; attempt < 2; ++attempt) {
     dma_k(0); dma_v(0); dma_k(1); dma_v(1); dma_k(2);
     init(A, 0);
     init(Bk, 1);
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory"); st.prev = t0_; }
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0_)::"memory");
 #endif
-    const int t_exact = attempt == 0 ? (nt < 2 ? nt : 2) : nt;
+    const int t_exact = REDO ? nt : (nt < 2 ? nt : 2);
     if (wave_idle) {
         for (int t = 0; t < nt; ++t) {
             __builtin_amdgcn_s_barrier();
@@ -417,7 +417,8 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
         };
         int t = 0;
         for (; t < t_exact; ++t) iteration(t, exact_form{});
-        for (; t < nt; ++t) iteration(t, steady_form{});
+        if (!REDO)
+            for (; t < nt; ++t) iteration(t, steady_form{});
     }
 
 #ifdef LTXMI_ATTN_STAMPS
@@ -449,8 +450,9 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     // the out-of-range pieces of tiles >= nt are still landing (as zeros): drain them before the rings are reused (as the
     // output scratch, or by the redo's stream); then agree on the redo
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (!REDO) {
     bool outgrown = false;
-    if (attempt == 0 && t_exact < nt && !wave_idle) {
+    if (t_exact < nt && !wave_idle) {
         // a row sum or an accumulator of magnitude >= 2^100 (or inf / NaN: the test is on the exponent bits, the file is
         // built with -fno-honor-nans) = a score outgrew its row's fixed reference.  Not only overflow: 1 / l for l > 2^126 is
         // a denormal and flushes to zero; a legitimate l is at most (keys) x 2^(a few bits).
@@ -473,7 +475,10 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     __builtin_amdgcn_sched_barrier(0);
     const int redo = *redo_flag;
     __builtin_amdgcn_s_barrier();
-    if (attempt == 1 || redo == 0) break;
+    if (redo != 0) return true;
+    } else {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- epilogue: O = O^T / l, through a per-wave LDS scratch so that rows leave whole (attention.hip)
@@ -501,6 +506,19 @@ __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     };
     store(A, 0);
     store(Bk, 1);
+    return false;
+}
+
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    if (!attn_pipe_item<false>(p, tid, smem)) return;
+    // (rare) the item again, exact form throughout.  The thread id is laundered through an empty asm so that nothing the first
+    // run derived from it is kept alive -- i.e. spilled -- across its loops for this path's sake: everything is recomputed.
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));
+    attn_pipe_item<true>(p, tid2, smem);
 }
 
 }  // namespace pipe
