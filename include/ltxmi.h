@@ -186,6 +186,11 @@ int ltxmi_attention_fuses_qnorm(int32_t B, int32_t H, int32_t Lq, int32_t Lk, in
 int ltxmi_attention_kernel_id(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t head_dim, int32_t has_key_bias,
                               int64_t k_stride_l, int64_t v_stride_l);
 
+/* The same row factor as a launch of its own (cross-attention's q, which has no k pass of equal row count to ride on):
+ * rstd_out[r] = rsqrt(sum_j rowsumsq[r * rowsumsq_ld + j] / norm_dim + norm_eps), j < rowsumsq_blocks, r < rows. */
+int ltxmi_rowsumsq_rstd_f32(const float* rowsumsq, int64_t rowsumsq_ld, int32_t rowsumsq_blocks, int32_t rows,
+                            int32_t norm_dim, float norm_eps, float* rstd_out, void* stream);
+
 /* Ulysses send buffer in one pass (sequence-parallel self-attention, xdit_context_parallel.py:149-184 of the reference
  * for Wan; here for the LTX DiT): q/k RMSNorm(weight) + interleaved RoPE exactly as ltxmi_rmsnorm_rope_bf16 and v,
  * read from the packed projection qkv [B*Nl, 3 D] (row stride ld, row = b * Nl + n) and written destination-major:

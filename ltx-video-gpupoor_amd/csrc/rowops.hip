@@ -388,6 +388,42 @@ static int rmsnorm_rope_launch(void* x, int64_t ldx, int32_t rows, int32_t D, co
                                const float* side_ss, int64_t side_ld, int32_t side_n, int32_t side_d, float side_eps,
                                float* side_rstd, void* stream);
 
+// rstd[r] = rsqrt(sum_j ss[r * ld + j] / norm_dim + eps): the row factor of an RMSNorm from per-64-column partial sums.  Eight
+// lanes per row, 16 bytes each (coalesced: a row of 32 partials is 128 B), reduced with three shuffles.
+__global__ __launch_bounds__(256) void rowsumsq_rstd_kernel(const float* __restrict__ ss, int64_t ld, int n, int rows, float inv_d,
+                                                            float eps, float* __restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int r = t >> 3, part = t & 7;
+    float acc = 0.f;
+    if (r < rows) {
+        const float* p = ss + (int64_t)r * ld;
+        if ((n & 3) == 0 && ((ld & 3) == 0) && (((uintptr_t)ss) & 15) == 0) {
+            for (int j = 4 * part; j < n; j += 32) {
+                const f32x4 v = *(const f32x4*)(p + j);
+                acc += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        } else {
+            for (int j = part; j < n; j += 8) acc += p[j];
+        }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (r < rows && part == 0) out[r] = rsqrtf(acc * inv_d + eps);
+}
+
+extern "C" int ltxmi_rowsumsq_rstd_f32(const float* rowsumsq, int64_t rowsumsq_ld, int32_t rowsumsq_blocks, int32_t rows,
+                                       int32_t norm_dim, float norm_eps, float* rstd_out, void* stream) {
+    LTXMI_REQUIRE(rowsumsq && rstd_out, LTXMI_ERR_INVALID_ARG, "ltxmi_rowsumsq_rstd_f32: NULL argument");
+    LTXMI_REQUIRE(rows > 0 && rowsumsq_blocks > 0 && norm_dim > 0 && rowsumsq_ld >= rowsumsq_blocks &&
+                      ((((uintptr_t)rowsumsq) | ((uintptr_t)rstd_out)) & 3) == 0,
+                  LTXMI_ERR_INVALID_ARG, "ltxmi_rowsumsq_rstd_f32: bad geometry (rows %d, blocks %d, ld %lld, dim %d)", rows,
+                  rowsumsq_blocks, (long long)rowsumsq_ld, norm_dim);
+    hipLaunchKernelGGL(rowsumsq_rstd_kernel, dim3((rows * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, rowsumsq, rowsumsq_ld,
+                       rowsumsq_blocks, rows, 1.0f / (float)norm_dim, norm_eps, rstd_out);
+    return check_launch("ltxmi_rowsumsq_rstd_f32");
+}
+
 extern "C" int ltxmi_rmsnorm_rope_bf16(void* x, int64_t ldx, int32_t rows, int32_t D, const void* weight, float eps,
                                        const void* cos_tab, const void* sin_tab, int64_t ld_tab,
                                        int32_t rope_period, void* stream) {

@@ -58,6 +58,7 @@ SIGNATURES = {
                                         c_int64, c_int, c_void_p]),
     "ltxmi_rmsnorm_rope_rstd_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p,
                                              c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "ltxmi_rowsumsq_rstd_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "ltxmi_qkv_norm_rope_pack_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                               c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "ltxmi_attention_fwd_bf16": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),

@@ -28,7 +28,7 @@ from .attention_seam import pay_attention
 BF16 = torch.bfloat16
 
 
-FUSE_CROSS_ATTENTION_Q = False     # see AttnProcessor2_0 (cross-attention branch)
+FUSE_CROSS_ATTENTION_Q = True      # see AttnProcessor2_0 (cross-attention branch)
 
 
 class SkipLayerStrategy(Enum):          # ltx_video/utils/skip_layer_strategy.py:4-8
@@ -270,10 +270,11 @@ class AttnProcessor2_0:
             v3 = qkv.view(B, N, 3 * D)[:, :, 2 * D:]
         else:
             Bk, Lk, _ = encoder_hidden_states.shape
-            # q's RMSNorm could be applied by the attention kernel while it loads q, as in self-attention (the kernel
-            # supports it and is tested).  With 256 text keys it does not pay: every head's workgroups re-derive the
-            # row factor and the kernel's short life is mostly prologue -- measured 83.2 us fused against 20.9 + 60.9 us
-            # (tools/xattn_time.py) -- so q keeps a pass of its own here.
+            # q's RMSNorm is applied by the attention kernel while it loads q, as in self-attention.  With 256 text keys the
+            # kernel's short life is mostly prologue, and with every head's workgroups re-deriving the row factor from 32
+            # partials the fusion did not pay (round 2: 83.2 us fused against 20.9 + 60.9 us).  With the factor finalised per
+            # row by a launch of its own it does: 8.4 + 67.3 us against 21.2 + 63.2 us (tools/xattn_time.py; -0.28 ms per
+            # step, tools/bench_xattn_fuse.py).
             fuse_q = FUSE_CROSS_ATTENTION_Q and D % 64 == 0 and bool(ops.attention_fuses_qnorm(B, H, N, Lk, dh, attention_mask is not None))
             ss = torch.empty((B * N, D // 64), dtype=torch.float32, device=x2.device) if fuse_q else None
             q2 = ops.gemm(x2, attn.to_q.weight, attn.to_q.bias, rowsumsq=ss, rowsumsq_cols=D if fuse_q else 0)   # [B*N, D]
@@ -296,7 +297,8 @@ class AttnProcessor2_0:
             else:
                 kv = hit[0]
             if fuse_q:
-                q_fused = ((ss, attn.q_norm.weight, attn.q_norm.eps), None)
+                # one factor per row (a 3 us launch over 2 MB) instead of a 122 MB pass over q
+                q_fused = ((ops.rowsumsq_rstd(ss, D, attn.q_norm.eps), attn.q_norm.weight, attn.q_norm.eps), None)
             else:
                 ops.rmsnorm_rope_(q2, attn.q_norm.weight, attn.q_norm.eps)
             q4 = q2.view(B, N, H, dh)

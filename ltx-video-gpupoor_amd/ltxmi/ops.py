@@ -179,6 +179,17 @@ def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, rope_period=0, rstd_of=Non
     return x
 
 
+def rowsumsq_rstd(ss, norm_dim, eps, out=None):
+    """fp32 [rows, blocks] partial sums of squares -> fp32 [rows] RMSNorm factors rsqrt(sum / norm_dim + eps)."""
+    if ss.dtype != torch.float32 or ss.dim() != 2 or ss.stride(1) != 1 or not ss.is_cuda:
+        raise ValueError("ltxmi.rowsumsq_rstd: expected CUDA fp32 sums [rows, blocks]")
+    rows = ss.shape[0]
+    out = torch.empty((rows,), dtype=torch.float32, device=ss.device) if out is None else out
+    check(lib.ltxmi_rowsumsq_rstd_f32(_ptr(ss), ss.stride(0), ss.shape[1], rows, norm_dim, eps, _ptr(out), _stream()),
+          "ltxmi_rowsumsq_rstd_f32")
+    return out
+
+
 def attention_fuses_qnorm(B, H, Lq, Lk, dh, has_key_bias=False):
     """Whether ``attention(..., q_norm=...)`` is available for this shape (every shape ``attention`` accepts)."""
     return bool(lib.ltxmi_attention_fuses_qnorm(B, H, Lq, Lk, dh, int(has_key_bias)))

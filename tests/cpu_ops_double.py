@@ -93,6 +93,14 @@ def rmsnorm_rope_(x, weight, eps, cos=None, sin=None, rope_period=0, rstd_of=Non
     return x
 
 
+def rowsumsq_rstd(ss, norm_dim, eps, out=None):
+    r = torch.rsqrt(ss.float().sum(-1) / norm_dim + eps)
+    if out is None:
+        return r
+    out.copy_(r)
+    return out
+
+
 def attention_fuses_qnorm(B, H, Lq, Lk, dh, has_key_bias=False):
     return False            # the double keeps q's normalisation as a pass of its own (both forms are kernel-tested on the GPU)
 
@@ -172,7 +180,7 @@ def stg_blend_grouped_(a, v, m_f32):
 
 
 NAMES = ["gemm", "norm_modulate", "rmsnorm_rope_", "attention_fuses_qnorm", "attention_kernel_id", "attention", "qkv_norm_rope_pack", "silu",
-         "timestep_embedding", "stg_blend_", "stg_blend_grouped_"]
+         "timestep_embedding", "stg_blend_", "stg_blend_grouped_", "rowsumsq_rstd"]
 
 
 def install():

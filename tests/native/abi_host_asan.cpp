@@ -138,6 +138,9 @@ int main() {
     expect_fail(ltxmi_rmsnorm_rope_rstd_bf16(p, 6144, 4992, 2048, p, 1e-6f, p, p, 2048, 4992, nullptr, 32, 32, 2048, 1e-6f, pf, nullptr), "rmsnorm_rope_rstd(NULL sums)", LTXMI_ERR_INVALID_ARG);
     expect_fail(ltxmi_rmsnorm_rope_rstd_bf16(p, 6144, 4992, 2048, p, 1e-6f, p, p, 2048, 4992, pf, 16, 32, 2048, 1e-6f, pf, nullptr), "rmsnorm_rope_rstd(ld < blocks)", LTXMI_ERR_INVALID_ARG);
     expect_fail(ltxmi_rmsnorm_rope_rstd_bf16(p, 6144, 4992, 2048, p, 1e-6f, p, p, 2048, 4992, pf, 32, 32, 2048, 1e-6f, pf, nullptr), "rmsnorm_rope_rstd(no device)");
+    expect_fail(ltxmi_rowsumsq_rstd_f32(nullptr, 32, 32, 4992, 2048, 1e-6f, pf, nullptr), "rowsumsq_rstd(NULL)", LTXMI_ERR_INVALID_ARG);
+    expect_fail(ltxmi_rowsumsq_rstd_f32(pf, 16, 32, 4992, 2048, 1e-6f, pf, nullptr), "rowsumsq_rstd(ld < blocks)", LTXMI_ERR_INVALID_ARG);
+    expect_fail(ltxmi_rowsumsq_rstd_f32(pf, 32, 32, 4992, 2048, 1e-6f, pf, nullptr), "rowsumsq_rstd(no device)");
     expect_fail(ltxmi_qkv_norm_rope_pack_bf16(nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, 0.f, nullptr, nullptr, 0, 0, nullptr, nullptr), "pack(NULL)");
     expect_fail(ltxmi_qkv_norm_rope_pack_bf16(p, 6144, 3, 2496, 2048, 2, p, p, 1e-6f, p, p, 2048, 2496, p, nullptr), "pack(no device)");
     expect_fail(ltxmi_qkv_norm_rope_pack_bf16(p, 6144, 3, 2496, 2048, 3, p, p, 1e-6f, p, p, 2048, 2496, p, nullptr), "pack(P not dividing the heads)");

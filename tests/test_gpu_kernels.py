@@ -970,6 +970,14 @@ def test_attention_q_norm_on_load_generic_kernel(B, H, dh, Lq, Lk, bias, rope):
     fused = ops.attention(q.view(B, Lq, H, dh), k, v, key_bias=kb, q_norm=(ss, wq, 1e-6),
                           rope=(cos, sin, Lq) if rope else None)
     check(fused, two_pass.float(), rel_l2=2e-3, maxrel=1.6e-2, what="q finished on load (generic kernel) vs two passes")
+    # the row factor as ONE float per row from its own launch (ltxmi_rowsumsq_rstd_f32; cross-attention's q): the factor
+    # against fp32, attention against the partial-sums form
+    rstd = ops.rowsumsq_rstd(ss, D, 1e-6)
+    want = torch.rsqrt(q.float().pow(2).mean(-1) + 1e-6)
+    assert float(((rstd - want) / want).abs().max()) < 1e-5
+    fused_r = ops.attention(q.view(B, Lq, H, dh), k, v, key_bias=kb, q_norm=(rstd, wq, 1e-6),
+                            rope=(cos, sin, Lq) if rope else None)
+    check(fused_r, fused.float(), rel_l2=5e-4, maxrel=8e-3, what="row factor vs partial sums (generic kernel)")
 
 
 # ------------------------------------------------ kernels of the zero-copy Ulysses exchange, on ONE device

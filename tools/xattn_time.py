@@ -38,3 +38,7 @@ def t(fn, n=30):
 qq = q.clone()
 print(f"rmsnorm pass {t(lambda: ops.rmsnorm_rope_(qq, w, 1e-6)):.1f} us + attention {t(lambda: ops.attention(q.view(B, Lq, H, dh), k, v, out=out, key_bias=kb)):.1f} us"
       f"   |   attention with q normalised on load {t(lambda: ops.attention(q.view(B, Lq, H, dh), k, v, out=out, key_bias=kb, q_norm=(ss, w, 1e-6))):.1f} us")
+# round 3: one factor per row (ltxmi_rowsumsq_rstd_f32, a launch of its own) instead of 32 partials re-summed per workgroup
+rstd = torch.empty(B * Lq, device=dev, dtype=torch.float32)
+print(f"row-factor launch {t(lambda: ops.rowsumsq_rstd(ss, D, 1e-6, out=rstd)):.1f} us + attention with q normalised on load from it "
+      f"{t(lambda: ops.attention(q.view(B, Lq, H, dh), k, v, out=out, key_bias=kb, q_norm=(rstd, w, 1e-6))):.1f} us")
