@@ -52,7 +52,8 @@ constexpr int CD_HALO_ROWS = CD_HT * CD_HY * CD_HX;            // 720
 constexpr int CD_HALO_BYTES = CD_HALO_ROWS * 128;               // 92160
 constexpr int CD_W_BYTES = 128 * 128;                           // one tap: 128 output channels x 64 input channels
 constexpr int CD_WSTAGES = 3;
-constexpr int CD_SMEM = CD_HALO_BYTES + CD_WSTAGES * CD_W_BYTES; // 141312
+constexpr int CD_ROWTAB_BYTES = CD_HALO_ROWS * 4;               // per halo row: byte offset of its source row (or the 'zero' sentinel)
+constexpr int CD_SMEM = CD_HALO_BYTES + CD_WSTAGES * CD_W_BYTES + CD_ROWTAB_BYTES; 
 
 // EPI: 0 plain store, 1 y = conv + add, 2 depth-to-space store (+ residual), as the implicit-GEMM kernel's epilogues
 template <int EPI>
@@ -77,67 +78,100 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     const int t0 = tt * CD_TT, y0 = ty * CD_TY, x0 = tx * CD_TX, n0 = nb * 128;
 
     // ---- halo loader: piece q = rows 8q .. 8q+7; lane -> (row 8q + lane>>3, LDS slot lane&7, source slot ^ row&7).
-    // Where a halo row comes from depends on the tile only, not on the 64-channel chunk: the per-lane byte offsets of
-    // this wave's 11-12 pieces are computed ONCE (stamps: the div/mod/clamp arithmetic per piece made the issue of a
-    // chunk's halo take 4500 cycles, with no MFMA running), and a chunk's loads are then one buffer_load ... lds per
-    // piece with the chunk's channel offset as the scalar offset.  Rows that are zero padding get an offset past the
-    // descriptor's range: the hardware delivers zeros.
-    constexpr int HP = (CD_HALO_ROWS / 8 + 7) / 8;                           // pieces per wave (90 pieces over 8 waves: 12)
+    // Where a halo row comes from depends on the tile only, not on the 64-channel chunk: the byte offset of every halo row's
+    // source row is computed ONCE per tile into a 720-entry table in LDS (stamps of round 2: the div/mod/clamp arithmetic per
+    // piece made the issue of a chunk's halo take 4500 cycles, with no MFMA running; round 2 kept twelve offsets per lane in
+    // registers, and picking one of them by a run-time piece number became an indexed load from scratch memory).  A piece is
+    // then one ds_read_b32 (well ahead of its use) + one add + one buffer_load ... lds with the chunk's channel offset as the
+    // scalar offset.  Rows that are zero padding get an offset past the descriptor's range: the hardware delivers zeros.
     const int64_t x_bytes = (int64_t)p.B * p.T * p.H * p.W * p.Cin * 2;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)p.x, 0, (int)(x_bytes < 0x7ffffff0ll ? x_bytes : 0x7ffffff0ll), 0x00020000);
-    const int64_t xb = (int64_t)b * p.T * p.H * p.W * p.Cin;
-    uint32_t hoff[HP];
-#pragma unroll
-    for (int k = 0; k < HP; ++k) {
-        const int q = wave + 8 * k;
-        const int r = q * 8 + (lane >> 3);
-        const int hx = r % CD_HX, hy = (r / CD_HX) % CD_HY, ht = r / (CD_HX * CD_HY);
-        int ti = t0 + ht - p.tpad, yi = y0 + hy - 1, xi = x0 + hx - 1;
-        const bool toob = (ti < 0) | (ti >= p.T);
-        const bool oob = (yi < 0) | (yi >= p.H) | (xi < 0) | (xi >= p.W);
-        ti = ti < 0 ? 0 : (ti >= p.T ? p.T - 1 : ti);
-        yi = yi < 0 ? 0 : (yi >= p.H ? p.H - 1 : yi);
-        xi = xi < 0 ? 0 : (xi >= p.W ? p.W - 1 : xi);
-        const int64_t e = xb + ((int64_t)(ti * p.H + yi) * p.W + xi) * p.Cin + (((lane & 7) ^ (r & 7)) << 3);
-        const bool zero = (oob && !p.pad_replicate) | (toob && p.tzero) | (q >= CD_HALO_ROWS / 8);
-        hoff[k] = zero ? 0x7ffffff0u : (uint32_t)(e * 2);
+    uint32_t* rowtab = (uint32_t*)(smem + CD_HALO_BYTES + CD_WSTAGES * CD_W_BYTES);
+    {
+        const int64_t xb = (int64_t)b * p.T * p.H * p.W * p.Cin;
+        for (int r = tid; r < CD_HALO_ROWS; r += 512) {
+            const int hx = r % CD_HX, hy = (r / CD_HX) % CD_HY, ht = r / (CD_HX * CD_HY);
+            int ti = t0 + ht - p.tpad, yi = y0 + hy - 1, xi = x0 + hx - 1;
+            const bool toob = (ti < 0) | (ti >= p.T);
+            const bool oob = (yi < 0) | (yi >= p.H) | (xi < 0) | (xi >= p.W);
+            ti = ti < 0 ? 0 : (ti >= p.T ? p.T - 1 : ti);
+            yi = yi < 0 ? 0 : (yi >= p.H ? p.H - 1 : yi);
+            xi = xi < 0 ? 0 : (xi >= p.W ? p.W - 1 : xi);
+            const int64_t e = xb + ((int64_t)(ti * p.H + yi) * p.W + xi) * p.Cin;
+            const bool zero = (oob && !p.pad_replicate) | (toob && p.tzero);
+            rowtab[r] = zero ? 0x7ffffff0u : (uint32_t)(e * 2);
+        }
     }
-    // pieces [q_lo, 90) of a chunk's halo
-    auto load_halo = [&](int c0, int q_lo) {
-#pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            const int q = wave + 8 * k;
-            if (q >= q_lo && q < CD_HALO_ROWS / 8) blds16(x_rsrc, halo + q * 1024, hoff[k], c0 * 2);
-        }
-    };
+    // (a lane's row within a piece is lane >> 3 whatever the piece, so its 16-byte slot term is a per-lane constant; added to
+    // the sentinel it stays out of range)
+    const uint32_t hslot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
     // The halo is four t-planes of 180 rows, and the taps run dt-major: after tap 8 (dt = 0 done) plane 0 is dead, after
-    // tap 17 plane 1 is.  The NEXT chunk's rows for those planes are requested under the remaining taps -- pieces 0..21
-    // (rows 0..175) one per wave and tap at taps 9..11, pieces 22..44 (rows 176..359) at taps 18..21 -- so that only
-    // planes 2 and 3 (pieces 45..89) are loaded with the matrix pipe idle at the start of a chunk.
-    constexpr int Q_PLANE0 = 22, Q_PLANE1 = 45;
-    auto prefetch_halo = [&](int tap, int c_next) __attribute__((always_inline)) -> bool {
-        int k, lo, hi;
-        if (tap >= 9 && tap <= 11) { k = tap - 9; lo = 0; hi = Q_PLANE0; }
-        else if (tap >= 18 && tap <= 21) { k = tap - 16; lo = Q_PLANE0; hi = Q_PLANE1; }
-        else return false;
-        const int q = wave + 8 * k;
-        if (q < lo || q >= hi) return false;
-        // (a select, not hoff[k]: a runtime index would put the array into scratch memory)
-        const uint32_t off = k == 0 ? hoff[0] : k == 1 ? hoff[1] : k == 2 ? hoff[2] : k == 3 ? hoff[3] : k == 4 ? hoff[4] : hoff[5];
-        blds16(x_rsrc, halo + q * 1024, off, c_next * 2);
-        return true;
+    // tap 17 plane 1 is, and planes 2 and 3 are first read by tap 9 (whose fragments are fetched under tap 8).  So the halo
+    // STREAMS, at most one piece per wave and tap: the chunk's own planes 2 and 3 (pieces 45..89) under its taps 0..6, the
+    // NEXT chunk's rows 0..175 (pieces 0..21) under taps 9..11 and its rows 176..359 (pieces 22..44) under taps 18..21.  A
+    // chunk boundary has no load phase of its own (round 2: 1950 cycles of issue + 2200 of waiting per chunk with the matrix
+    // pipe idle); only the first chunk's planes 0 and 1 are loaded in front of the tap stream.
+    constexpr int Q_PLANE0 = 22, Q_PLANE1 = 45, Q_END = CD_HALO_ROWS / 8;
+    // Source row offset of a tap's piece: read from the table at the end of the tap before (unconditionally), turned into the
+    // lane's offset behind that tap's second MFMA block, used at its end.  The read is issued from inline asm and waited for by
+    // hand: as a C++ load hipcc put s_waitcnt lgkmcnt(0) in front of it (at the end of every tap, behind the fragment reads
+    // just issued).  An LDS read hipcc does not know about only makes its own counted waits more conservative: LDS
+    // operations complete in order.
+    uint32_t hoff_nx = 0;
+    const uint32_t rowtab_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)rowtab) + (uint32_t)(lane >> 3) * 4;
+    auto read_hoff = [&](int q) __attribute__((always_inline)) {
+        const uint32_t a = rowtab_lds + (uint32_t)(q * 32);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(hoff_nx) : "v"(a) : "memory");
     };
-    // ---- weights of one tap and chunk: rows n0 .. n0+127 of w [Cout, 27*Cin], 64 channels at (tap*Cin + c0)
-    const int wrow0 = (wave * 2) * 8 + (lane >> 3);
-    auto load_w = [&](int stage, int tap, int c0) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = wrow0 + j * 8;
-            const int n = min(n0 + row, p.Cout - 1);                      // rows past Cout: recomputed, never stored
-            const uint16_t* src = p.w + (int64_t)n * (27 * p.Cin) + tap * p.Cin + c0 + (((lane & 7) ^ (row & 7)) << 3);
-            glds16(src, wst + stage * CD_W_BYTES + (wave * 2 + j) * 1024);
-        }
+    // ---- weights of one tap and chunk: rows n0 .. n0+127 of w [Cout, 27*Cin], 64 channels at (tap*Cin + c0), through a
+    // descriptor over the block's rows (rows past Cout are out of range and arrive as zeros: never stored), so that a piece is
+    // one VALU add + one buffer_load ... lds with the (tap, chunk) offset in a scalar.
+    const int w_row_bytes = 27 * p.Cin * 2;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.w + (int64_t)n0 * 27 * p.Cin), 0, min(128, p.Cout - n0) * w_row_bytes, 0x00020000);
+    constexpr int WPP = 2;                                       // weight pieces per wave and tap: pieces 2 wave, 2 wave + 1
+    const int wp0 = wave * 2;
+    const uint32_t woff0 = (uint32_t)((wp0 * 8 + (lane >> 3)) * w_row_bytes + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
+    auto load_w_piece = [&](int stage, int soff, int j) __attribute__((always_inline)) {   // piece j of this wave
+        blds16(w_rsrc, wst + stage * CD_W_BYTES + (wp0 + j) * 1024, woff0 + (uint32_t)(j * 8 * w_row_bytes), soff);
+    };
+
+    // ---- what a tap of the (chunk, tap) stream does besides its MFMAs -- all wave-uniform, all a function of (tap, chunk).
+    // It is worked out ONE TAP AHEAD, in one piece behind the third MFMA block of the tap before, so that nothing but the
+    // issue of the weight loads sits between a barrier and the first MFMA behind it.  Measured (in-process A/B against round
+    // 2's kernel, sum over a decode's convolutions): everything at the top of the tap -5 %; behind block 2 +2.0..2.7 %; the
+    // same behind block 0 / 1 / 3 -3.5 / -2.2 / -2.0 %; an incremental form (~60 instead of ~85 scalar instructions) spread
+    // over blocks 0..2 -0.4 %, in one piece behind block 2 +1.2 % (profiles/r03_conv_stream.log).
+    struct Ctl {
+        int w_soff, w_stage;     // weights two taps ahead in the stream: scalar byte offset (< 0: nothing to issue), stage
+        int h_q, h_soff;         // this tap's halo piece (-1: none) and its chunk's byte offset
+        int n_off, n_stage;      // next tap: halo row offset of its (dt, dy, dx), weight stage
+        int n_q;                 // next tap's piece slot in the row table (clamped; whether there is a piece: its own h_q)
+    };
+    auto piece_slot = [&](int tap) __attribute__((always_inline)) -> int {
+        return tap <= 6 ? tap + 5 : tap <= 11 ? tap - 9 : tap - 16;                 // (meaningful inside the three windows)
+    };
+    auto make_ctl = [&](int tap, int c0) __attribute__((always_inline)) -> Ctl {
+        Ctl k;
+        const int c_next = c0 + 64 < p.Cin ? c0 + 64 : -1;
+        const bool wrap2 = tap >= 25;                                              // tap + 2 belongs to the next chunk
+        const int t2 = wrap2 ? tap - 25 : tap + 2, c2 = wrap2 ? c_next : c0;
+        k.w_soff = c2 >= 0 ? (t2 * p.Cin + c2) * 2 : -1;
+        k.w_stage = t2 % CD_WSTAGES;                                               // (27 taps = 9 turns of the ring)
+        const bool own = tap <= 6;                                                 // the chunk's own planes 2 and 3
+        const bool win = own | ((tap >= 9) & (tap <= 11)) | ((tap >= 18) & (tap <= 21));
+        const int lo = own ? Q_PLANE1 : tap <= 11 ? 0 : Q_PLANE0, hi = own ? Q_END : tap <= 11 ? Q_PLANE0 : Q_PLANE1;
+        const int c = own ? c0 : c_next;
+        const int q = wave + 8 * piece_slot(tap);
+        k.h_q = (win & (c >= 0) & (q >= lo) & (q < hi)) ? q : -1;
+        k.h_soff = c * 2;
+        const int tn = tap < 26 ? tap + 1 : 0;                                     // behind a chunk's last tap: the next chunk's tap 0
+        k.n_off = ((tn / 9) * CD_HY + (tn / 3) % 3) * CD_HX + tn % 3;
+        k.n_stage = tn % CD_WSTAGES;
+        const int qn = wave + 8 * piece_slot(tn);
+        k.n_q = qn < 0 ? 0 : qn < Q_END ? qn : Q_END - 1;
+        return k;
     };
 
     // ---- fragment geometry.  A block i of this wave = positions wm*64 + i*16 + (lane & 15): one (t, y) row of
@@ -160,7 +194,7 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     auto read_frags = [&](auto set_tag, int tap) {
         constexpr int S = decltype(set_tag)::value;
         const int dt = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-        const char* ws = wst + (tap % CD_WSTAGES) * CD_W_BYTES;
+        const char* ws = wst + (tap % CD_WSTAGES) * CD_W_BYTES;     // (only called for tap 0 of the stream)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int blk = wm * 4 + i;                                  // (t, y) row of the tile
@@ -192,8 +226,8 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
 #endif
     // keep1: the youngest request of this wave is a prefetched halo piece of the NEXT chunk -- it may stay in flight
     // across the barrier (the wait of the following tap covers it: requests complete in order)
-    auto sync_all = [&](bool keep1 = false) {
-        CSTAMP(0);                                               // [0] issue of loads + fragment reads + MFMAs of a tap
+    auto sync_all = [&](bool keep1) {
+        CSTAMP(0);                                               // [0] table read + issue of the halo piece
         if (keep1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CSTAMP(1);                                               // [1] wait for this wave's LDS-DMA
@@ -204,14 +238,27 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
         asm volatile("s_barrier" ::: "memory");
         CSTAMP(2);                                               // [2] barrier
     };
-    // one tap: weights of tap + 2 start streaming, fragments of tap + 1 are read, MFMAs of tap
-    // a wave whose 64 output channels all lie beyond Cout only helps with the loads and barriers
+    // One tap of the (chunk, tap) stream: the weights two taps ahead start streaming (this chunk's, or the next chunk's first
+    // two), the fragments of the next tap are read between this tap's MFMA blocks, at most one halo piece goes out at the end.
+    // A wave whose 64 output channels all lie beyond Cout only helps with the loads and barriers.
+    // (the stream's very last tap reads "next" fragments too -- of a tap 0 that does not exist, from LDS that nothing writes
+    // any more; they are never used: no branch sits between the MFMA blocks)
     const bool active = n0 + wn * 64 < p.Cout;
-    auto tap_body = [&](int tap, int c0, int c_next, auto cur_tag, auto nxt_tag) __attribute__((always_inline)) {
+    int s_tap = 0, s_c0 = 0;                                     // the stream position
+    Ctl cur = make_ctl(0, 0);
+    auto tap_body = [&](auto cur_tag, auto nxt_tag) __attribute__((always_inline)) {
         CSTAMP(3);
-        if (tap + 2 < 27) load_w((tap + 2) % CD_WSTAGES, tap + 2, c0);
-        const bool pf = c_next >= 0 && prefetch_halo(tap, c_next);     // AFTER the weight pieces: it is the youngest request
-        CSTAMP(6);                                               // [6] issue of the weight pieces (+ a prefetched halo piece)
+        if (cur.w_soff >= 0) {
+#pragma unroll
+            for (int j = 0; j < WPP; ++j) load_w_piece(cur.w_stage, cur.w_soff, j);
+        }
+        CSTAMP(6);                                               // [6] issue of the weight pieces
+        // the stream position after this tap; laundered per path below, so that what is derived from it stays where it is
+        // written (as a common subexpression of both paths hipcc hoists it in front of the tap's first MFMA)
+        int tap1 = s_tap + 1, c01 = s_c0;
+        if (tap1 == 27) { tap1 = 0; c01 += 64; }
+        Ctl nxt;
+        uint32_t hfin;
         if (active) {
             // The 16 fragment reads of tap + 1 are NOT issued as a burst in front of this tap's MFMAs: right after the
             // barrier all 8 waves would queue 128 ds_read_b128 (512 LDS cycles, and a wave can have only 15 in flight)
@@ -219,9 +266,7 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
             // Each position block's 8 MFMAs go first, the reads of the next tap's same block (and one weight block) follow.
             constexpr int S = decltype(cur_tag)::value;          // register sets of this tap's / the next tap's fragments
             constexpr int N = decltype(nxt_tag)::value;
-            const int tn = tap + 1;
-            const int dt = tn / 9, dy = (tn / 3) % 3, dx = tn % 3;
-            const char* ws = wst + (tn % CD_WSTAGES) * CD_W_BYTES;
+            const char* ws = wst + cur.n_stage * CD_W_BYTES;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -229,42 +274,72 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[S][j][ks], af[S][i][ks], acc[i][j], 0, 0, 0);
-                if (tn < 27) {
-                    const int blk = wm * 4 + i;                                  // (t, y) row of the tile
-                    const int row = (((blk >> 3) + dt) * CD_HY + ((blk & 7) + dy)) * CD_HX + dx + frow;
+                const int blk = wm * 4 + i;                                      // (t, y) row of the tile
+                const int row = ((blk >> 3) * CD_HY + (blk & 7)) * CD_HX + cur.n_off + frow;
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        af[N][i][ks] = *(const bf16x8*)(halo + row * 128 + (((fchunk + 4 * ks) ^ (row & 7)) << 4));
-                        bfr[N][i][ks] = *(const bf16x8*)(ws + (b_off[i] ^ (ks << 6)));
-                    }
+                for (int ks = 0; ks < 2; ++ks) {
+                    af[N][i][ks] = *(const bf16x8*)(halo + row * 128 + (((fchunk + 4 * ks) ^ (row & 7)) << 4));
+                    bfr[N][i][ks] = *(const bf16x8*)(ws + (b_off[i] ^ (ks << 6)));
+                }
+                if (i == 1) {
+                    // the table read is older than the 8 fragment reads this tap has issued so far (LDS reads return in order)
+                    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                    hfin = hoff_nx + hslot;
+                    asm volatile("" : "+v"(hfin));
+                }
+                if (i == 2) {
+                    asm volatile("" : "+s"(tap1), "+s"(c01));
+                    nxt = make_ctl(tap1, c01);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             CSTAMP(7);                                           // [7] MFMAs with the next tap's reads in their shadow
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            uint32_t t = hoff_nx;
+            asm volatile("" : "+v"(t), "+s"(tap1), "+s"(c01));
+            hfin = t + hslot;
+            nxt = make_ctl(tap1, c01);
         }
-        sync_all(pf);
+        read_hoff(cur.n_q);
+        // this tap's halo piece goes out as the wave's youngest request: it may stay in flight across the barrier (the wait of
+        // the following tap covers it)
+        if (cur.h_q >= 0) blds16(x_rsrc, halo + cur.h_q * 1024, hfin, cur.h_soff);
+        sync_all(cur.h_q >= 0);
+        cur = nxt;
+        s_tap = tap1;
+        s_c0 = c01;
     };
 
+    // ---- in front of the stream: planes 0 and 1 of the first chunk's halo, the weights of its taps 0 and 1
     const int nchunks = p.Cin >> 6;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int c0 = ch * 64;
-        CSTAMP(3);
-        load_halo(c0, ch == 0 ? 0 : Q_PLANE1);                  // (planes 0 and 1 of a later chunk arrived under the previous one)
-        load_w(0, 0, c0);
-        load_w(1, 1, c0);
-        CSTAMP(4);                                               // [4] issue of a chunk's halo + first weights
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        CSTAMP(5);                                               // [5] ... until they have landed everywhere
-        if (active) read_frags(s0_t{}, 0);
-        const int c_next = ch + 1 < nchunks ? c0 + 64 : -1;
-        // all 27 taps unrolled: the tap's halo offset (dt, dy, dx), its weight stage and its share of the halo prefetch
-        // become constants -- no scalar arithmetic or branching between a barrier and the first MFMA behind it
-for (int tap = 0; tap < 26; tap += 2) {
-            tap_body(tap, c0, c_next, s0_t{}, s1_t{});
-            tap_body(tap + 1, c0, c_next, s1_t{}, s0_t{});
+    CSTAMP(3);
+    __syncthreads();                                             // the row table is complete
+#pragma unroll
+    for (int k = 0; k < (Q_PLANE1 + 7) / 8; ++k) {
+        const int q = wave + 8 * k;
+        if (q < Q_PLANE1) blds16(x_rsrc, halo + q * 1024, rowtab[q * 8 + (lane >> 3)] + hslot, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < WPP; ++j) {
+        load_w_piece(0, 0, j);
+        load_w_piece(1, p.Cin * 2, j);
+    }
+    CSTAMP(4);                                                   // [4] issue of the first half halo + first weights
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    CSTAMP(5);                                                   // [5] ... until they have landed everywhere
+    if (active) read_frags(s0_t{}, 0);
+    read_hoff(wave + 8 * piece_slot(0) < Q_END ? wave + 8 * piece_slot(0) : Q_END - 1);
+    // The (chunk, tap) stream is walked two taps at a time (the fragment register sets alternate per tap; a chunk has 27 taps,
+    // so the pairs straddle the chunk boundaries)
+    {
+        const int total = 27 * nchunks;
+        for (int g = 0; g + 1 < total; g += 2) {
+            tap_body(s0_t{}, s1_t{});
+            tap_body(s1_t{}, s0_t{});
         }
-        tap_body(26, c0, c_next, s0_t{}, s1_t{});
+        if (total & 1) tap_body(s0_t{}, s1_t{});
     }
 
     // ---- epilogue: bias (+ add), bf16, through a 4 KB per-wave LDS scratch (the halo is free after the last

@@ -742,7 +742,8 @@ def test_gemm_full_size_linearity_ff1_shape():
 
 # ---------------------------------------------------------------- direct convolution path
 @pytest.mark.parametrize("causal,mode,tzero", [(True, "zeros", False), (False, "replicate", False), (False, "zeros", True)])
-@pytest.mark.parametrize("cin,cout,with_add", [(64, 128, False), (128, 256, True), (128, 48, False), (64, 200, True)])
+@pytest.mark.parametrize("cin,cout,with_add", [(64, 128, False), (128, 256, True), (128, 48, False), (64, 200, True),
+                                               (192, 128, True)])      # 1, 2 and 3 chunks of 64 input channels (odd / even tap streams)
 def test_conv3d_direct_path(causal, mode, tzero, cin, cout, with_add):
     """Shapes the direct (LDS-halo) convolution takes (>= 16384 positions, >= 512 workgroups, Cout % 128 == 0),
     with partial tiles on every axis (T = 5, H = 36, W = 100 against 2 x 8 x 16 tiles)."""

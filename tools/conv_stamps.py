@@ -33,8 +33,11 @@ for (T, Hh, W, cin, cout, name) in [(97, 128, 192, 128, 128, "128->128 full res"
     tiles = 1.0
     taps = chunks * 27
     med = lambda a: float(np.median(a))
-    print(f"{name:18s}: per tap (median over waves): DMA issue {med(d[..., 6] / taps):5.0f}  reads issue+land {med(d[..., 7] / taps):5.0f}  MFMA {med(d[..., 0] / taps):6.0f}  vmcnt {med(d[..., 1] / taps):5.0f}  barrier {med(d[..., 2] / taps):5.0f}"
-          f"  = {med((d[..., 0] + d[..., 1] + d[..., 2] + d[..., 6] + d[..., 7]) / taps):6.0f} cycles (MFMA-bound: 1024 per SIMD pair);  per chunk: halo issue {med(d[..., 4] / chunks):6.0f}"
-          f"  halo wait {med(d[..., 5] / chunks):6.0f};  rest per chunk {med(d[..., 3] / chunks):6.0f};  chunks {med(chunks):.0f}", flush=True)
-    w0, w7 = d[:, 0], d[:, 7]
-    print(f"      wave 0: issue+MFMA {med(w0[:, 0] / taps[:, 0]):6.0f} barrier {med(w0[:, 2] / taps[:, 0]):5.0f}   wave 7: issue+MFMA {med(w7[:, 0] / taps[:, 7]):6.0f} barrier {med(w7[:, 2] / taps[:, 7]):5.0f}")
+    # [3] barrier release -> top of the tap body, [6] weight DMA issue, [7] MFMA blocks + next tap's fragment reads,
+    # [0] table read + halo piece issue, [1] vmcnt wait, [2] barrier wait;  [4] / [5]: the once-per-tile load phase
+    names = [(3, "loop"), (6, "w-issue"), (7, "mfma+reads"), (0, "halo-issue"), (1, "vmcnt"), (2, "barrier")]
+    tot = sum(d[..., i] for i, _ in names) / taps
+    print(f"{name:18s}: per tap, median over the first round's waves: " + "  ".join(f"{n} {med(d[..., i] / taps):5.0f}" for i, n in names)
+          + f"  = {med(tot):6.0f} cycles (matrix pipe: 1024 per SIMD pair);  per tile: first loads issue {med(d[..., 4]):6.0f} wait {med(d[..., 5]):6.0f}", flush=True)
+    for wv in range(8):
+        print(f"      wave {wv}: " + "  ".join(f"{n} {med(d[:, wv, i] / taps[:, wv]):5.0f}" for i, n in names))
