@@ -47,7 +47,7 @@ def main():
             out["ff1_gemm_hbm_bytes_per_launch"] = r["hbm_bytes_per_launch"]
             break
     # the bench's roofline kernel: pipelined self-attention (the launch with the largest grid = the DiT's self-attention)
-    att = [r for r in rows if "attn_pipe_kernel" in r["kernel"]]
+    att = [r for r in rows if "attn_pipe_kernel" in r["kernel"] or "attn_pipe_persistent_kernel" in r["kernel"]]
     if att:
         out["attention_hbm_bytes_per_launch"] = max(att, key=lambda r: r["launches"])["hbm_bytes_per_launch"]
     # the VAE legs' roofline kernel: the direct convolution with the plain store and the largest grid (128 -> 128 at the
