@@ -989,7 +989,8 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
                   "ltxmi_gemm_bf16: algo %d not in {0, 128, 256}", force_tile);
     if (force_tile == 128) return launch_tile<128, 128, 2, 2, 0>(p, epi, s, "ltxmi_gemm_bf16");
     constexpr long persist_min = 128;      // measured: 128 > 256 > 384 tiles for M = 4992 .. 9984
-    if (a->M >= 1024 && a->N >= 256 && t256 >= persist_min) {
+    // (M >= 768: the stacked text K/V projection of a forward -- 3 x 256 text rows against every layer's [to_k; to_v])
+    if (a->M >= 768 && a->N >= 256 && t256 >= persist_min) {
         const bool fits32 = ((int64_t)a->M * a->ldc * 2 < (1ll << 32)) && ((int64_t)256 * a->lda * 2 < (1ll << 31)) &&
                             ((int64_t)256 * a->ldw * 2 < (1ll << 31));
         if (a->K >= 128 && fits32 && force_tile != 256)

@@ -288,6 +288,15 @@ class AttnProcessor2_0:
             cache = attn.__dict__.setdefault("_text_kv_cache", {})
             hit = cache.get(key) if ops.STEP_INVARIANT_CACHING else None
             if hit is None:
+                # this forward's stacked projection (Transformer3DModel._stacked_text_kv): rows of the FULL batch's text states;
+                # a block run on the leading rows of the batch takes the leading rows
+                ready = attn.__dict__.pop("_text_kv_ready", None)
+                if ready is not None:
+                    full, full_version, kv_full = ready
+                    if (ehs.data_ptr() == full.data_ptr() and ehs.shape[1:] == full.shape[1:] and Bk <= full.shape[0]
+                            and ehs.dtype == full.dtype and ehs.is_contiguous() and ops.tensor_version(full) == full_version):
+                        hit = (kv_full[:Bk * Lk],)
+            if hit is None:
                 kv = ops.gemm(ehs.reshape(Bk * Lk, -1), wkv, bkv)                  # [B*Lk, 2D]
                 ops.rmsnorm_rope_(kv[:, :D], attn.k_norm.weight, attn.k_norm.eps)
                 if len(cache) >= 4:

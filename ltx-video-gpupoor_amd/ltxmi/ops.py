@@ -474,6 +474,11 @@ def ndhwc_to_ncdhw(x, c0, C, std=None, mean=None):
 # bench.py switches it off for its headline number so that every step of the timed region does all the work
 # the reference's step does.
 STEP_INVARIANT_CACHING = True
+# Without that cache every step projects the prompt through every layer's to_k / to_v (the reference's own schedule:
+# attention.py:1042-1048 once per block and step).  768 text rows make a skinny GEMM per layer (192 workgroups of 128 x 128 on 256
+# CUs, 11 % matrix-pipe busy); Transformer3DModel.forward therefore runs ALL layers' projections as one GEMM against the
+# stacked weights before the block loop (same kernels' arithmetic, bit-identical values) and hands each block its slice.
+STACKED_TEXT_KV = True
 
 
 def set_step_invariant_caching(enabled: bool):

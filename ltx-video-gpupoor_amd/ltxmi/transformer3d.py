@@ -190,6 +190,34 @@ class Transformer3DModel(nn.Module):
             sin_freq = torch.cat([torch.zeros_like(cos_freq[:, :, : dim % 6]), sin_freq], dim=-1)
         return cos_freq.to(self.dtype).contiguous(), sin_freq.to(self.dtype).contiguous()
 
+    def _stacked_text_kv(self, ehs):
+        """Every layer's text keys / values of this forward in ONE GEMM (attention.py:1042-1048 runs the projections once per
+        block): ``ehs`` [B, T, D] against the stacked [to_k; to_v] of all cross-attention layers -> [B T, L 2D], each layer's
+        key half RMS-normalised in place (k_norm, :1040-1041), each block's attn2 handed its column slice (a strided view, read
+        by the attention kernel through its strides).  The values are those of the per-layer projections bit for bit: all GEMM
+        kernels accumulate over K in the same order.  Stacked weights: built once, rebuilt when any source tensor changes."""
+        blocks = [b for b in self.transformer_blocks if getattr(b, "attn2", None) is not None]
+        if not blocks or ehs.dim() != 3 or not ehs.is_contiguous():
+            return
+        packs = [b.attn2.packed_kv() for b in blocks]
+        if any(bk is None for _, bk in packs) or len({tuple(w.shape) for w, _ in packs}) != 1:
+            return
+        key = tuple((w.data_ptr(), ops.tensor_version(w), bk.data_ptr(), ops.tensor_version(bk)) for w, bk in packs)
+        st = self.__dict__.get("_stacked_kv_weights")
+        if st is None or st[0] != key:
+            with torch.no_grad():
+                st = (key, torch.cat([w for w, _ in packs], 0).contiguous(), torch.cat([bk for _, bk in packs], 0).contiguous(),
+                      packs)                                                        # (packs kept alive: no address reuse)
+            self.__dict__["_stacked_kv_weights"] = st
+        _, w_all, b_all, _ = st
+        Bk, Lk, _ = ehs.shape
+        two_d = packs[0][0].shape[0]
+        kv_all = ops.gemm(ehs.reshape(Bk * Lk, -1), w_all, b_all)                       # [B T, L 2D]
+        for i, b in enumerate(blocks):
+            kv = kv_all[:, i * two_d:(i + 1) * two_d]
+            ops.rmsnorm_rope_(kv[:, :two_d // 2], b.attn2.k_norm.weight, b.attn2.k_norm.eps)
+            b.attn2.__dict__["_text_kv_ready"] = (ehs, ops.tensor_version(ehs), kv)
+
     def _run_blocks_microbatched(self, hidden_states, slices, freqs_cis, attention_mask, encoder_hidden_states,
                                  encoder_attention_mask, temb, cross_attention_kwargs, class_labels, layer_mask,
                                  skip_layer_strategy, ltxv_model):
@@ -296,6 +324,9 @@ class Transformer3DModel(nn.Module):
                 if ops.STEP_INVARIANT_CACHING:
                     cache[key] = hit
             encoder_hidden_states = hit[0]
+
+        if joint_pass and ops.STACKED_TEXT_KV and not ops.STEP_INVARIANT_CACHING and encoder_hidden_states is not None:
+            self._stacked_text_kv(encoder_hidden_states)
 
         host_rows = None
         if skip_layer_mask is not None:

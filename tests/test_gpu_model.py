@@ -143,6 +143,49 @@ def test_transformer_joint_pass_false_matches_joint():
     assert rel(b, a) < 4e-3
 
 
+@pytest.mark.parametrize("alias", [0, 2])
+def test_transformer_stacked_text_kv_is_bit_identical(alias):
+    """Without the per-generation cache a forward projects the prompt through ALL layers' [to_k; to_v] in one stacked GEMM
+    (ops.STACKED_TEXT_KV) instead of one skinny GEMM per block: same values bit for bit, with the full batch and with the
+    leading rows a block sees under ``stg_alias_blocks``; a stale hand-over (other prompt tensor, edited weights) is not used."""
+    from ltxmi import ops
+    grid = (2, 4, 6)
+    cfg, sd32, x, enc, mask, ts, frac = dit_case(2, 64, 4, grid, 3, 40, seed=5)
+    x[2], enc[2], mask[2], ts[2] = x[1], enc[1], mask[1], ts[1]
+    m = build_model(cfg, sd32)
+    fc = m.precompute_freqs_cis(frac.to(DEV))
+    encd = enc.to(DEV)
+    kw = dict(freqs_cis=fc, encoder_attention_mask=mask.to(DEV), timestep=ts.to(DEV), latent_shape=grid,
+              ltxv_model=_Holder(), return_dict=False, stg_alias_blocks=alias)
+    old = (ops.STEP_INVARIANT_CACHING, ops.STACKED_TEXT_KV)
+    try:
+        ops.set_step_invariant_caching(False)
+        ops.STACKED_TEXT_KV = False
+        ref = m(x.to(DEV), encoder_hidden_states=encd, **kw)[0]
+        ops.STACKED_TEXT_KV = True
+        out = m(x.to(DEV), encoder_hidden_states=encd, **kw)[0]
+        assert "_stacked_kv_weights" in m.__dict__                          # the stacked path ran ...
+        assert all("_text_kv_ready" not in b.attn2.__dict__ for b in m.transformer_blocks)   # ... and every block took its slice
+        assert torch.equal(out, ref)
+        # another prompt tensor: new projection, not the previous forward's
+        enc2 = (encd.float() * 0.5).to(encd.dtype)
+        ops.STACKED_TEXT_KV = False
+        ref2 = m(x.to(DEV), encoder_hidden_states=enc2, **kw)[0]
+        ops.STACKED_TEXT_KV = True
+        out2 = m(x.to(DEV), encoder_hidden_states=enc2, **kw)[0]
+        assert torch.equal(out2, ref2) and not torch.equal(out2, out)
+        # an in-place weight edit rebuilds the stack
+        with torch.no_grad():
+            m.transformer_blocks[1].attn2.to_k.weight.mul_(0.5)
+        out3 = m(x.to(DEV), encoder_hidden_states=encd, **kw)[0]
+        ops.STACKED_TEXT_KV = False
+        ref3 = m(x.to(DEV), encoder_hidden_states=encd, **kw)[0]
+        assert torch.equal(out3, ref3) and not torch.equal(out3, out)
+    finally:
+        ops.set_step_invariant_caching(old[0])
+        ops.STACKED_TEXT_KV = old[1]
+
+
 def test_transformer_stg_row_alias_is_bit_identical():
     """stg_alias_blocks: the perturbed row computed as a copy of the text row up to the first skipped block
     gives bit-identical output to computing all three rows."""
