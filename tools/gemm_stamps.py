@@ -44,6 +44,8 @@ for (M, N, K, epi, name) in [(14976, 8192, 2048, ops.EPI_GELU_TANH, "ff1"), (149
         print(f"{name} {M}x{N}x{K} algo {al}: per {unit} (median over waves): MFMA phase A {pa:6.0f}  vmcnt {vm:5.0f}  barrier {bar:5.0f}  "
               f"phase B {pb:6.0f}{extra}  = {pa + vm + bar + pb + (med(d[..., 4] / n) if al == 4 else 0):6.0f} cycles (pipe-bound: {bound});  "
               f"epilogue/tile {med(d[..., 6] / tiles):7.0f};  rest/tile {med(d[..., 4] / tiles):7.0f};  tiles/WG {med(tiles):.1f}", flush=True)
-        w0, wl = d[:, 0], d[:, nw - 1]
-        print(f"      wave 0: A {med(w0[:, 0] / n[:, 0]):6.0f} barrier {med(w0[:, 2] / n[:, 0]):5.0f} B {med(w0[:, 3] / n[:, 0]):6.0f}   "
-              f"wave {nw - 1}: A {med(wl[:, 0] / n[:, nw - 1]):6.0f} barrier {med(wl[:, 2] / n[:, nw - 1]):5.0f} B {med(wl[:, 3] / n[:, nw - 1]):6.0f}")
+        # per wave (round 3: waves 0-3 issue all LDS-DMA, waves 4-7 only compute)
+        for wv in range(nw):
+            x = d[:, wv]
+            print(f"      wave {wv}: A {med(x[:, 0] / n[:, wv]):6.0f}  vmcnt {med(x[:, 1] / n[:, wv]):5.0f}  barrier {med(x[:, 2] / n[:, wv]):5.0f}  "
+                  f"B {med(x[:, 3] / n[:, wv]):6.0f}  epilogue/tile {med(x[:, 6] / tiles[:, wv]):7.0f}")
