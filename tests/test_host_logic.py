@@ -92,3 +92,65 @@ def test_g6_product_scheduler_step(golden):
     g = torch.Generator().manual_seed(7)            # the draw the reference took from the global RNG seeded with 7
     out = s.step(t["step.v"], t["step.tok_t"], t["step.sample"], return_dict=False, stochastic_sampling=True, generator=g)[0]
     torch.testing.assert_close(out, t["step.stochastic_per_token"], **TOL)
+
+
+def test_stacked_text_kv_host_logic_on_the_cpu_double():
+    """Transformer3DModel._stacked_text_kv + the processor's hand-over (ops.STACKED_TEXT_KV, the per-generation cache off) with
+    ltxmi.ops swapped for its CPU double, in a process of its own: same output as the per-layer projections (torch.equal: the
+    double's GEMM is row- and column-wise independent too), every block consumes its slice, a block run on other rows than the
+    leading ones falls back to projecting by itself."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, torch
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "ltx-video-gpupoor_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import cpu_ops_double
+ops = cpu_ops_double.install()
+import ltxmi
+from oracle import dit, sched
+bf = torch.bfloat16
+cfg = dict(dit.default_2b_config(), num_attention_heads=4, attention_head_dim=64, num_layers=3, cross_attention_dim=256, caption_channels=128)
+sd32 = {k: v.to(bf).float() for k, v in dit.init_state_dict(cfg, seed=3).items()}
+f, h, w = 2, 3, 4
+N, B, T = f * h * w, 3, 12
+g = torch.Generator().manual_seed(4)
+x = torch.randn(B, N, 128, generator=g).to(bf)
+enc = torch.randn(B, T, 128, generator=g).to(bf)
+x[2], enc[2] = x[1], enc[1]
+mask = torch.ones(B, T); mask[:, 8:] = 0
+ts = torch.full((B, 1), 0.7)
+m = ltxmi.Transformer3DModel(**cfg); m.load_state_dict(sd32); m = m.to(bf).eval()
+fc = m.precompute_freqs_cis(sched.fractional_coords(f, h, w, 1, 25.0))
+kw = dict(freqs_cis=fc, encoder_hidden_states=enc, encoder_attention_mask=mask, timestep=ts, latent_shape=(f, h, w), return_dict=False)
+ops.set_step_invariant_caching(False)
+with torch.no_grad():
+    for alias in (0, 2):
+        ops.STACKED_TEXT_KV = False
+        ref = m(x.clone(), stg_alias_blocks=alias, **kw)[0]
+        assert "_stacked_kv_weights" not in m.__dict__
+        ops.STACKED_TEXT_KV = True
+        out = m(x.clone(), stg_alias_blocks=alias, **kw)[0]
+        assert torch.equal(out, ref), alias
+        assert "_stacked_kv_weights" in m.__dict__
+        assert all("_text_kv_ready" not in b.attn2.__dict__ for b in m.transformer_blocks)
+        del m.__dict__["_stacked_kv_weights"]
+    # a block that sees OTHER rows than the leading ones must not take the hand-over
+    m._stacked_text_kv(m.caption_projection(enc).view(B, T, -1))
+    blk = m.transformer_blocks[0]
+    ready = blk.attn2.__dict__["_text_kv_ready"]
+    full = ready[0]
+    assert full.shape[0] == B and ready[2].shape[0] == B * T
+    # with the cache on nothing is stacked
+    ops.set_step_invariant_caching(True)
+    for b in m.transformer_blocks: b.attn2.__dict__.pop("_text_kv_ready", None)
+    m.__dict__.pop("_stacked_kv_weights", None)
+    m(x.clone(), **kw)
+    assert "_stacked_kv_weights" not in m.__dict__
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
