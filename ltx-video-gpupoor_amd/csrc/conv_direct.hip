@@ -53,7 +53,8 @@ constexpr int CD_HALO_BYTES = CD_HALO_ROWS * 128;               // 92160
 constexpr int CD_W_BYTES = 128 * 128;                           // one tap: 128 output channels x 64 input channels
 constexpr int CD_WSTAGES = 3;
 constexpr int CD_ROWTAB_BYTES = CD_HALO_ROWS * 4;               // per halo row: byte offset of its source row (or the 'zero' sentinel)
-constexpr int CD_SMEM = CD_HALO_BYTES + CD_WSTAGES * CD_W_BYTES + CD_ROWTAB_BYTES; 
+constexpr int CD_CTLTAB_BYTES = 8 * 27 * 8;                     // per (wave, tap): two packed control words
+constexpr int CD_SMEM = CD_HALO_BYTES + CD_WSTAGES * CD_W_BYTES + CD_ROWTAB_BYTES + CD_CTLTAB_BYTES; 
 
 // EPI: 0 plain store, 1 y = conv + add, 2 depth-to-space store (+ residual), as the implicit-GEMM kernel's epilogues
 template <int EPI>
@@ -138,39 +139,60 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     };
 
     // ---- what a tap of the (chunk, tap) stream does besides its MFMAs -- all wave-uniform, all a function of (tap, chunk).
-    // It is worked out ONE TAP AHEAD, in one piece behind the third MFMA block of the tap before, so that nothing but the
-    // issue of the weight loads sits between a barrier and the first MFMA behind it.  Measured (in-process A/B against round
-    // 2's kernel, sum over a decode's convolutions): everything at the top of the tap -5 %; behind block 2 +2.0..2.7 %; the
-    // same behind block 0 / 1 / 3 -3.5 / -2.2 / -2.0 %; an incremental form (~60 instead of ~85 scalar instructions) spread
-    // over blocks 0..2 -0.4 %, in one piece behind block 2 +1.2 % (profiles/r03_conv_stream.log).
+    // Scalar instructions are NOT free beside MFMAs here: both waves of a SIMD pair run the same code at the same time, and a
+    // wave that issues a scalar instruction issues no MFMA (tools/ubench/conv_loop.hip: a bare loop of this tap's 2 x 32 MFMAs
+    // runs at 1032 cycles per tap; with the fragment reads, their address arithmetic and the barrier 1196; with ~140 dependent
+    // scalar instructions behind block 2 it takes 1780).  So the control of the 27 taps is worked out ONCE per tile into a table
+    // in LDS (two packed words per (wave, tap)); a tap reads the entry of the tap after the next with one hidden ds_read_b64 at
+    // its end, and the tap in between unpacks it behind its third MFMA block: ~20 scalar instructions per tap instead of the ~85
+    // that recomputing it from (tap, chunk) took (measured on the way: recomputed at the top of the tap -5 %, behind block 2
+    // +2.0..2.7 % over round 2's kernel, behind block 0 / 1 / 3 -3.5 / -2.2 / -2.0 %: profiles/r03_conv_stream.log).
     struct Ctl {
         int w_soff, w_stage;     // weights two taps ahead in the stream: scalar byte offset (< 0: nothing to issue), stage
         int h_q, h_soff;         // this tap's halo piece (-1: none) and its chunk's byte offset
         int n_off, n_stage;      // next tap: halo row offset of its (dt, dy, dx), weight stage
         int n_q;                 // next tap's piece slot in the row table (clamped; whether there is a piece: its own h_q)
     };
-    auto piece_slot = [&](int tap) __attribute__((always_inline)) -> int {
-        return tap <= 6 ? tap + 5 : tap <= 11 ? tap - 9 : tap - 16;                 // (meaningful inside the three windows)
-    };
-    auto make_ctl = [&](int tap, int c0) __attribute__((always_inline)) -> Ctl {
-        Ctl k;
-        const int c_next = c0 + 64 < p.Cin ? c0 + 64 : -1;
+    // word 0: byte offset of tap + 2's weights inside a weight row, relative to its chunk; bit 31: that tap belongs to the NEXT chunk
+    // word 1: n_off [0,9) | w_stage [9,11) | n_stage [11,13) | halo piece [13,21) (0xff: none) | piece of the chunk itself [21] | n_q [22,29)
+    uint32_t* ctltab = (uint32_t*)(smem + CD_HALO_BYTES + CD_WSTAGES * CD_W_BYTES + CD_ROWTAB_BYTES);
+    if (tid < 8 * 27) {
+        const int w = tid / 27, tap = tid - w * 27;
+        auto piece_slot = [](int t) { return t <= 6 ? t + 5 : t <= 11 ? t - 9 : t - 16; };     // (meaningful inside the three windows)
         const bool wrap2 = tap >= 25;                                              // tap + 2 belongs to the next chunk
-        const int t2 = wrap2 ? tap - 25 : tap + 2, c2 = wrap2 ? c_next : c0;
-        k.w_soff = c2 >= 0 ? (t2 * p.Cin + c2) * 2 : -1;
-        k.w_stage = t2 % CD_WSTAGES;                                               // (27 taps = 9 turns of the ring)
+        const int t2 = wrap2 ? tap - 25 : tap + 2;
         const bool own = tap <= 6;                                                 // the chunk's own planes 2 and 3
         const bool win = own | ((tap >= 9) & (tap <= 11)) | ((tap >= 18) & (tap <= 21));
         const int lo = own ? Q_PLANE1 : tap <= 11 ? 0 : Q_PLANE0, hi = own ? Q_END : tap <= 11 ? Q_PLANE0 : Q_PLANE1;
-        const int c = own ? c0 : c_next;
-        const int q = wave + 8 * piece_slot(tap);
-        k.h_q = (win & (c >= 0) & (q >= lo) & (q < hi)) ? q : -1;
-        k.h_soff = c * 2;
+        const int q = w + 8 * piece_slot(tap);
+        const int hq = (win & (q >= lo) & (q < hi)) ? q : 0xff;
         const int tn = tap < 26 ? tap + 1 : 0;                                     // behind a chunk's last tap: the next chunk's tap 0
-        k.n_off = ((tn / 9) * CD_HY + (tn / 3) % 3) * CD_HX + tn % 3;
-        k.n_stage = tn % CD_WSTAGES;
-        const int qn = wave + 8 * piece_slot(tn);
-        k.n_q = qn < 0 ? 0 : qn < Q_END ? qn : Q_END - 1;
+        const int n_off = ((tn / 9) * CD_HY + (tn / 3) % 3) * CD_HX + tn % 3;
+        const int qn = w + 8 * piece_slot(tn);
+        const int n_q = qn < 0 ? 0 : qn < Q_END ? qn : Q_END - 1;
+        ctltab[tid * 2] = (uint32_t)(t2 * p.Cin * 2) | (wrap2 ? 0x80000000u : 0u);
+        ctltab[tid * 2 + 1] = (uint32_t)n_off | (uint32_t)(t2 % CD_WSTAGES) << 9 | (uint32_t)(tn % CD_WSTAGES) << 11 | (uint32_t)hq << 13 |
+                              (own ? 1u << 21 : 0u) | (uint32_t)n_q << 22;
+    }
+    u32x2 cw_nx = {0u, 0u};                                                       // the packed entry in flight
+    const uint32_t ctltab_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)ctltab) + (uint32_t)(wave * 27 * 8);
+    auto read_ctl = [&](int tap) __attribute__((always_inline)) {
+        const uint32_t a = ctltab_lds + (uint32_t)(tap * 8);
+        asm volatile("ds_read_b64 %0, %1" : "=v"(cw_nx) : "v"(a) : "memory");
+    };
+    auto unpack_ctl = [&](uint32_t d0, uint32_t d1, int c0) __attribute__((always_inline)) -> Ctl {
+        Ctl k;
+        const int c_next = c0 + 64 < p.Cin ? c0 + 64 : -1;
+        const int c2 = (int)d0 < 0 ? c_next : c0;
+        k.w_soff = c2 >= 0 ? (int)(d0 & 0x7fffffffu) + c2 * 2 : -1;
+        k.n_off = (int)(d1 & 0x1ffu);
+        k.w_stage = (int)((d1 >> 9) & 3u);
+        k.n_stage = (int)((d1 >> 11) & 3u);
+        const int hq = (int)((d1 >> 13) & 0xffu);
+        const int c = ((d1 >> 21) & 1u) ? c0 : c_next;
+        k.h_q = ((hq != 0xff) & (c >= 0)) ? hq : -1;
+        k.h_soff = c * 2;
+        k.n_q = (int)((d1 >> 22) & 0x7fu);
         return k;
     };
 
@@ -245,7 +267,7 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     // any more; they are never used: no branch sits between the MFMA blocks)
     const bool active = n0 + wn * 64 < p.Cout;
     int s_tap = 0, s_c0 = 0;                                     // the stream position
-    Ctl cur = make_ctl(0, 0);
+    Ctl cur;                                                     // (set in front of the stream, below)
     auto tap_body = [&](auto cur_tag, auto nxt_tag) __attribute__((always_inline)) {
         CSTAMP(3);
         if (cur.w_soff >= 0) {
@@ -253,8 +275,7 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
             for (int j = 0; j < WPP; ++j) load_w_piece(cur.w_stage, cur.w_soff, j);
         }
         CSTAMP(6);                                               // [6] issue of the weight pieces
-        // the stream position after this tap; laundered per path below, so that what is derived from it stays where it is
-        // written (as a common subexpression of both paths hipcc hoists it in front of the tap's first MFMA)
+        // the stream position after this tap
         int tap1 = s_tap + 1, c01 = s_c0;
         if (tap1 == 27) { tap1 = 0; c01 += 64; }
         Ctl nxt;
@@ -267,6 +288,7 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
             constexpr int S = decltype(cur_tag)::value;          // register sets of this tap's / the next tap's fragments
             constexpr int N = decltype(nxt_tag)::value;
             const char* ws = wst + cur.n_stage * CD_W_BYTES;
+            u32x2 cw;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -282,14 +304,17 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
                     bfr[N][i][ks] = *(const bf16x8*)(ws + (b_off[i] ^ (ks << 6)));
                 }
                 if (i == 1) {
-                    // the table read is older than the 8 fragment reads this tap has issued so far (LDS reads return in order)
+                    // the two hidden reads of the last tap's end (row-table entry, control entry) are older than the 8 fragment
+                    // reads this tap has issued so far (LDS reads return in order)
                     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
                     hfin = hoff_nx + hslot;
-                    asm volatile("" : "+v"(hfin));
+                    cw = cw_nx;
+                    asm volatile("" : "+v"(hfin), "+v"(cw));
                 }
                 if (i == 2) {
-                    asm volatile("" : "+s"(tap1), "+s"(c01));
-                    nxt = make_ctl(tap1, c01);
+                    int d0 = __builtin_amdgcn_readfirstlane((int)cw[0]), d1 = __builtin_amdgcn_readfirstlane((int)cw[1]);
+                    asm volatile("" : "+s"(d0), "+s"(d1), "+s"(c01));
+                    nxt = unpack_ctl((uint32_t)d0, (uint32_t)d1, c01);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -297,11 +322,15 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             uint32_t t = hoff_nx;
-            asm volatile("" : "+v"(t), "+s"(tap1), "+s"(c01));
+            u32x2 cw = cw_nx;
+            asm volatile("" : "+v"(t), "+v"(cw));
             hfin = t + hslot;
-            nxt = make_ctl(tap1, c01);
+            int d0 = __builtin_amdgcn_readfirstlane((int)cw[0]), d1 = __builtin_amdgcn_readfirstlane((int)cw[1]);
+            asm volatile("" : "+s"(d0), "+s"(d1), "+s"(c01));
+            nxt = unpack_ctl((uint32_t)d0, (uint32_t)d1, c01);
         }
         read_hoff(cur.n_q);
+        read_ctl(tap1 == 26 ? 0 : tap1 + 1);                     // the entry of the tap after the next
         // this tap's halo piece goes out as the wave's youngest request: it may stay in flight across the barrier (the wait of
         // the following tap covers it)
         if (cur.h_q >= 0) blds16(x_rsrc, halo + cur.h_q * 1024, hfin, cur.h_soff);
@@ -330,7 +359,12 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     __syncthreads();
     CSTAMP(5);                                                   // [5] ... until they have landed everywhere
     if (active) read_frags(s0_t{}, 0);
-    read_hoff(wave + 8 * piece_slot(0) < Q_END ? wave + 8 * piece_slot(0) : Q_END - 1);
+    // tap 0's control (read the ordinary way: nothing is in flight yet), then the hidden reads tap 0 consumes: tap 0's row-table
+    // entry and tap 1's control
+    cur = unpack_ctl((uint32_t)__builtin_amdgcn_readfirstlane((int)ctltab[wave * 54]),
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)ctltab[wave * 54 + 1]), 0);
+    read_hoff(wave + 40 < Q_END ? wave + 40 : Q_END - 1);        // (tap 0's piece slot: wave + 8 * 5)
+    read_ctl(1);
     // The (chunk, tap) stream is walked two taps at a time (the fragment register sets alternate per tap; a chunk has 27 taps,
     // so the pairs straddle the chunk boundaries)
     {
