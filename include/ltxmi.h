@@ -257,12 +257,15 @@ typedef struct ltxmi_conv3d_args {
      * nn.Conv3d(padding=1) -- the time axis is padded with zeros instead of replicated frames. */
     int32_t kernel_t, time_pad_zeros;
     int32_t algo;              /* 0 = implementation chosen by shape (the product setting); 1 = implicit GEMM;
-                                  2 = direct convolution (LTXMI_ERR_UNSUPPORTED if it does not take the shape).
-                                  Used by the parity tests to check the two implementations against each other. */
+                                  2 = direct convolution, form chosen by shape; 3 / 4 = direct convolution in its
+                                  four-wave (two workgroups per CU, Cout % 128 == 0) / eight-wave form whatever the
+                                  grid (LTXMI_ERR_UNSUPPORTED if the direct convolution does not take the shape).
+                                  Used by the parity tests to check the implementations against each other. */
 } ltxmi_conv3d_args;
 
 /* Two implementations behind this entry, chosen by shape: a direct convolution with the input halo
- * resident in LDS (stride 1, kernel_t 3, >= 128 workgroups) and an implicit GEMM (everything else).
+ * resident in LDS (stride 1, kernel_t 3, >= 128 workgroups; four waves per workgroup and two workgroups per CU where
+ * Cout is a multiple of 128, eight waves per workgroup otherwise) and an implicit GEMM (everything else).
  * Requirements for both: Cin % 64 == 0, Cout % 8 == 0, 16-byte aligned x / w. */
 int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* args, void* stream);
 

@@ -464,6 +464,313 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
     }
 }
 
+
+// =====================================================================================================================
+// Two workgroups per CU (round 3).  In the kernel above the two waves of a SIMD are waves w and w + 4 of ONE workgroup: they
+// run the same code at the same time, so every instruction that is not an MFMA -- the issue of the LDS-DMA pieces, the table
+// reads, the unpacking of the control, the address arithmetic, the barrier, a tile's load phase and epilogue -- is a hole in
+// the matrix pipe for both (tools/ubench/conv_loop.hip; the non-MFMA work of a tap takes ~1500 cycles by itself).  Here a
+// workgroup is FOUR waves (one per SIMD) on the same 256-position x 128-channel tile, its LDS footprint is halved by 32-channel
+// chunks (halo rows of 64 B), and two workgroups share a CU: a SIMD's two waves belong to different workgroups at different
+// points of their tiles, and one's holes are the other's MFMAs (the attention kernel's arrangement).
+//   wave tile    : 64 positions x 128 channels = 4 x 8 MFMA 16x16x32 blocks, ONE k-step (32 input channels) per tap; 128
+//                  accumulator registers.  Channel blocks outermost: a channel block's fragment is dead once its 4 MFMAs have
+//                  issued and the next tap's is read into it in place; the 4 position fragments are double-buffered
+//   per tap, wave: 32 MFMAs, 12 fragment reads, two 1-KB weight pieces, at most one halo piece
+//   LDS          : halo 4 planes x 192 rows (10 x 18 = 180, padded to whole 16-row pieces) x 64 B = 48 KB; weights 3 stages x
+//                  128 rows x 64 B = 24 KB; row table 3 KB; control table 0.9 KB  => 75.8 KB per workgroup.  64-byte rows:
+//                  16-byte slot s of row r holds source chunk s ^ 2 ((r >> 2) & 1), conflict-free for the 16-lane groups of
+//                  ds_read_b128 at every row alignment (exhaustive search over the swizzles of that form)
+// The stream, the tables and the epilogues are the kernel above with these constants.
+namespace v3 {
+constexpr int TT = 2, TY = 8, TX = 16;
+constexpr int HT = TT + 2, HY = TY + 2, HX = TX + 2;
+constexpr int PLANE_ROWS = HY * HX;                    // 180
+constexpr int PLANE_STRIDE = 192;                      // ... in whole 16-row pieces
+constexpr int HALO_ROWS = HT * PLANE_STRIDE;           // 768
+constexpr int ROW_B = 64;                              // 32 input channels
+constexpr int HALO_BYTES = HALO_ROWS * ROW_B;          // 49152
+constexpr int W_BYTES = 128 * ROW_B;                   // one tap: 128 output channels x 32 input channels
+constexpr int WSTAGES = 3;
+constexpr int ROWTAB_BYTES = HALO_ROWS * 4;
+constexpr int CTLTAB_BYTES = 4 * 27 * 8;
+constexpr int SMEM = HALO_BYTES + WSTAGES * W_BYTES + ROWTAB_BYTES + CTLTAB_BYTES;   // 77664
+constexpr int Q_PLANE0 = PLANE_STRIDE / 16, Q_PLANE1 = 2 * Q_PLANE0, Q_END = HALO_ROWS / 16;   // 12, 24, 48 pieces of 16 rows
+
+__device__ __forceinline__ int swz(int c, int r) { return c ^ (((r >> 2) & 1) << 1); }       // slot of source chunk c in LDS row r
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p) {
+    constexpr bool ADD = (EPI == 1), D2S = (EPI == 2);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* wst = smem + HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = the wave's position group (64 positions)
+
+    int id = blockIdx.x;
+    const int nb = id % p.tiles_n; id /= p.tiles_n;
+    const int tx = id % p.tiles_x; id /= p.tiles_x;
+    const int ty = id % p.tiles_y; id /= p.tiles_y;
+    const int tt = id % p.tiles_t;
+    const int b = id / p.tiles_t;
+    const int t0 = tt * TT, y0 = ty * TY, x0 = tx * TX, n0 = nb * 128;
+
+    // ---- row table (rows of zero padding, and the 12 rows that pad a plane to whole pieces: an offset past the descriptor)
+    const int64_t x_bytes = (int64_t)p.B * p.T * p.H * p.W * p.Cin * 2;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x, 0, (int)(x_bytes < 0x7ffffff0ll ? x_bytes : 0x7ffffff0ll), 0x00020000);
+    uint32_t* rowtab = (uint32_t*)(smem + HALO_BYTES + WSTAGES * W_BYTES);
+    {
+        const int64_t xb = (int64_t)b * p.T * p.H * p.W * p.Cin;
+        for (int r = tid; r < HALO_ROWS; r += 256) {
+            const int ht = r / PLANE_STRIDE, rr = r - ht * PLANE_STRIDE;
+            const int hy = rr / HX, hx = rr - hy * HX;
+            int ti = t0 + ht - p.tpad, yi = y0 + hy - 1, xi = x0 + hx - 1;
+            const bool toob = (ti < 0) | (ti >= p.T);
+            const bool oob = (yi < 0) | (yi >= p.H) | (xi < 0) | (xi >= p.W);
+            ti = ti < 0 ? 0 : (ti >= p.T ? p.T - 1 : ti);
+            yi = yi < 0 ? 0 : (yi >= p.H ? p.H - 1 : yi);
+            xi = xi < 0 ? 0 : (xi >= p.W ? p.W - 1 : xi);
+            const int64_t e = xb + ((int64_t)(ti * p.H + yi) * p.W + xi) * p.Cin;
+            const bool zero = (oob && !p.pad_replicate) | (toob && p.tzero) | (rr >= PLANE_ROWS);
+            rowtab[r] = zero ? 0x7ffffff0u : (uint32_t)(e * 2);
+        }
+    }
+    // ---- control table, per (wave, tap) -- see the kernel above
+    uint32_t* ctltab = (uint32_t*)(smem + HALO_BYTES + WSTAGES * W_BYTES + ROWTAB_BYTES);
+    if (tid < 4 * 27) {
+        const int w = tid / 27, tap = tid - w * 27;
+        // piece slots of a wave: its own planes 2 / 3 (24 pieces, 6 per wave) under taps 0..5, the next chunk's plane 0 (12
+        // pieces) under taps 9..11, its plane 1 under taps 18..20
+        auto piece_slot = [](int t) { return t <= 5 ? t + 6 : t <= 11 ? t - 9 : t - 15; };
+        const bool wrap2 = tap >= 25;
+        const int t2 = wrap2 ? tap - 25 : tap + 2;
+        const bool own = tap <= 5;
+        const bool win = own | ((tap >= 9) & (tap <= 11)) | ((tap >= 18) & (tap <= 20));
+        const int lo = own ? Q_PLANE1 : tap <= 11 ? 0 : Q_PLANE0, hi = own ? Q_END : tap <= 11 ? Q_PLANE0 : Q_PLANE1;
+        const int q = w + 4 * piece_slot(tap);
+        const int hq = (win & (q >= lo) & (q < hi)) ? q : 0xff;
+        const int tn = tap < 26 ? tap + 1 : 0;
+        const int n_off = (tn / 9) * PLANE_STRIDE + ((tn / 3) % 3) * HX + tn % 3;
+        const int qn = w + 4 * piece_slot(tn);
+        const int n_q = qn < 0 ? 0 : qn < Q_END ? qn : Q_END - 1;
+        ctltab[tid * 2] = (uint32_t)(t2 * p.Cin * 2) | (wrap2 ? 0x80000000u : 0u);
+        ctltab[tid * 2 + 1] = (uint32_t)n_off | (uint32_t)(t2 % WSTAGES) << 9 | (uint32_t)(tn % WSTAGES) << 11 | (uint32_t)hq << 13 |
+                              (own ? 1u << 21 : 0u) | (uint32_t)n_q << 22;
+    }
+    struct Ctl {
+        int w_soff, w_stage;
+        int h_q, h_soff;
+        int n_off, n_stage;
+        int n_q;
+    };
+    u32x2 cw_nx = {0u, 0u};
+    const uint32_t ctltab_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)ctltab) + (uint32_t)(wave * 27 * 8);
+    auto read_ctl = [&](int tap) __attribute__((always_inline)) {
+        const uint32_t a = ctltab_lds + (uint32_t)(tap * 8);
+        asm volatile("ds_read_b64 %0, %1" : "=v"(cw_nx) : "v"(a) : "memory");
+    };
+    auto unpack_ctl = [&](uint32_t d0, uint32_t d1, int c0) __attribute__((always_inline)) -> Ctl {
+        Ctl k;
+        const int c_next = c0 + 32 < p.Cin ? c0 + 32 : -1;
+        const int c2 = (int)d0 < 0 ? c_next : c0;
+        k.w_soff = c2 >= 0 ? (int)(d0 & 0x7fffffffu) + c2 * 2 : -1;
+        k.n_off = (int)(d1 & 0x1ffu);
+        k.w_stage = (int)((d1 >> 9) & 3u);
+        k.n_stage = (int)((d1 >> 11) & 3u);
+        const int hq = (int)((d1 >> 13) & 0xffu);
+        const int c = ((d1 >> 21) & 1u) ? c0 : c_next;
+        k.h_q = ((hq != 0xff) & (c >= 0)) ? hq : -1;
+        k.h_soff = c * 2;
+        k.n_q = (int)((d1 >> 22) & 0x7fu);
+        return k;
+    };
+    // a piece = 16 rows x 64 B: lane -> (row lane >> 2, LDS slot lane & 3); (row >> 2) & 1 of a lane's row is (lane >> 4) & 1
+    const uint32_t hslot = (uint32_t)(((lane & 3) ^ (((lane >> 4) & 1) << 1)) << 4);
+    uint32_t hoff_nx = 0;
+    const uint32_t rowtab_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)rowtab) + (uint32_t)(lane >> 2) * 4;
+    auto read_hoff = [&](int q) __attribute__((always_inline)) {
+        const uint32_t a = rowtab_lds + (uint32_t)(q * 64);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(hoff_nx) : "v"(a) : "memory");
+    };
+    // ---- weights: two pieces per wave and tap (rows 32 wave .. 32 wave + 31 of the block's 128)
+    const int w_row_bytes = 27 * p.Cin * 2;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.w + (int64_t)n0 * 27 * p.Cin), 0, min(128, p.Cout - n0) * w_row_bytes, 0x00020000);
+    const uint32_t woff0 = (uint32_t)((wave * 32 + (lane >> 2)) * w_row_bytes) + hslot;
+    auto load_w = [&](int stage, int soff) __attribute__((always_inline)) {
+        blds16(w_rsrc, wst + stage * W_BYTES + (wave * 2) * 1024, woff0, soff);
+        blds16(w_rsrc, wst + stage * W_BYTES + (wave * 2 + 1) * 1024, woff0 + (uint32_t)(16 * w_row_bytes), soff);
+    };
+
+    // ---- fragment geometry: position block i of this wave = positions wave*64 + i*16 + (lane & 15) = one (t, y) row
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int b_off0 = frow * ROW_B + (swz(fchunk, frow) << 4);            // channel block j: + j * 1024
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[2][4], bfr[8];
+    auto a_addr = [&](int i, int n_off) __attribute__((always_inline)) -> const char* {
+        const int blk = wave * 4 + i;
+        const int row = (blk >> 3) * PLANE_STRIDE + (blk & 7) * HX + n_off + frow;
+        return halo + row * ROW_B + (swz(fchunk, row) << 4);
+    };
+    using s0_t = std::integral_constant<int, 0>;
+    using s1_t = std::integral_constant<int, 1>;
+    auto sync_all = [&](bool keep1) {
+        if (keep1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+    };
+    int s_tap = 0, s_c0 = 0;
+    Ctl cur;
+    auto tap_body = [&](auto cur_tag, auto nxt_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(cur_tag)::value, N = decltype(nxt_tag)::value;
+        if (cur.w_soff >= 0) load_w(cur.w_stage, cur.w_soff);
+        int tap1 = s_tap + 1, c01 = s_c0;
+        if (tap1 == 27) { tap1 = 0; c01 += 32; }
+        Ctl nxt;
+        uint32_t hfin;
+        u32x2 cw;
+        const char* ws = wst + cur.n_stage * W_BYTES;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[S][i], acc[i][j], 0, 0, 0);
+            bfr[j] = *(const bf16x8*)(ws + b_off0 + j * 1024);                      // the next tap's channel block j, in place
+            if (j < 4) af[N][j] = *(const bf16x8*)a_addr(j, cur.n_off);
+            if (j == 3) {
+                // the two hidden reads of the last tap's end are older than the 8 fragment reads this tap has issued so far
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                hfin = hoff_nx + hslot;
+                cw = cw_nx;
+                asm volatile("" : "+v"(hfin), "+v"(cw));
+            }
+            if (j == 5) {
+                int d0 = __builtin_amdgcn_readfirstlane((int)cw[0]), d1 = __builtin_amdgcn_readfirstlane((int)cw[1]);
+                asm volatile("" : "+s"(d0), "+s"(d1), "+s"(c01));
+                nxt = unpack_ctl((uint32_t)d0, (uint32_t)d1, c01);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_hoff(cur.n_q);
+        read_ctl(tap1 == 26 ? 0 : tap1 + 1);
+        if (cur.h_q >= 0) blds16(x_rsrc, halo + cur.h_q * 1024, hfin, cur.h_soff);
+        sync_all(cur.h_q >= 0);
+        cur = nxt;
+        s_tap = tap1;
+        s_c0 = c01;
+    };
+
+    // ---- in front of the stream: planes 0 and 1 of the first chunk's halo, the weights of its taps 0 and 1
+    const int nchunks = p.Cin >> 5;
+    __syncthreads();                                             // the tables are complete
+#pragma unroll
+    for (int k = 0; k < Q_PLANE1 / 4; ++k) {
+        const int q = wave + 4 * k;
+        blds16(x_rsrc, halo + q * 1024, rowtab[q * 16 + (lane >> 2)] + hslot, 0);
+    }
+    load_w(0, 0);
+    load_w(1, p.Cin * 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[0][i] = *(const bf16x8*)a_addr(i, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bfr[j] = *(const bf16x8*)(wst + b_off0 + j * 1024);
+    cur = unpack_ctl((uint32_t)__builtin_amdgcn_readfirstlane((int)ctltab[wave * 54]),
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)ctltab[wave * 54 + 1]), 0);
+    read_hoff(wave + 24);                                        // tap 0's piece slot: wave + 4 * 6
+    read_ctl(1);
+    {
+        const int total = 27 * nchunks;
+        for (int g = 0; g + 1 < total; g += 2) {
+            tap_body(s0_t{}, s1_t{});
+            tap_body(s1_t{}, s0_t{});
+        }
+        if (total & 1) tap_body(s0_t{}, s1_t{});
+    }
+
+    // ---- epilogue: 32 positions x 64 channels at a time through the wave's 4-KB LDS scratch (the halo is free)
+    char* scr = smem + wave * 4096;
+    const int ecol = (lane >> 4) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        u32x2 bias_v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias_v[j] = *(const u32x2*)(p.bias + min(n0 + h * 64 + j * 16 + ecol, p.Cout - 4));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            u32x4 add_v[4];
+            if (ADD) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int pos = wave * 64 + c * 32 + t4 * 8 + (lane >> 3);
+                    const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1), xx = min(x0 + (pos & 15), p.W - 1);
+                    const int n = min(n0 + h * 64 + (lane & 7) * 8, p.Cout - 8);
+                    add_v[t4] = *(const u32x4*)(p.add + ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.Cout + n);
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * c + ii;
+                const int row_l = ii * 16 + frow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 a4 = acc[i][h * 4 + j];
+                    float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                    v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
+                    v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
+                    if (D2S && p.res) {
+                        const int pos = wave * 64 + i * 16 + frow;
+                        const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1);
+                        const int xx = min(x0 + (pos & 15), p.W - 1);
+                        const int Cp = p.Cout >> 3, pp = n0 / Cp, cp = n0 - pp * Cp + h * 64 + j * 16 + ecol;
+                        const uint16_t* rrow = p.res + ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.res_ch + pp;
+                        const int cm = p.res_ch >> 3;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bf2f(rrow[((cp + e) % cm) * 8]);
+                    }
+                    u32x2 o;
+                    o[0] = pack_bf16(v[0], v[1]);
+                    o[1] = pack_bf16(v[2], v[3]);
+                    const int chunk = j * 2 + (lane >> 5);
+                    *(u32x2*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4) + ((lane >> 4) & 1) * 8) = o;
+                }
+            }
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const int row_l = t4 * 8 + (lane >> 3), chunk = lane & 7;
+                u32x4 w = *(const u32x4*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4));
+                const int pos = wave * 64 + c * 32 + row_l;
+                const int t = t0 + (pos >> 7), yy = y0 + ((pos >> 4) & 7), xx = x0 + (pos & 15);
+                if (D2S) {
+                    const int Cp = p.Cout >> 3, pp = n0 / Cp, cp = n0 - pp * Cp + h * 64 + chunk * 8;
+                    const int to = 2 * t + (pp >> 2) - 1, yo = 2 * yy + ((pp >> 1) & 1), xo = 2 * xx + (pp & 1);
+                    if (t < p.T && yy < p.H && xx < p.W && to >= 0) {
+                        const int64_t opos = (((int64_t)b * (2 * p.T - 1) + to) * (2 * p.H) + yo) * (2 * p.W) + xo;
+                        *(u32x4*)(p.y + opos * Cp + cp) = w;
+                    }
+                } else if (t < p.T && yy < p.H && xx < p.W && n0 + h * 64 + chunk * 8 < p.Cout) {
+                    const int64_t off = ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.Cout + n0 + h * 64 + chunk * 8;
+                    if (ADD) {
+                        const u32x4 r = add_v[t4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            w[e] = pack_bf16(bf_lo(w[e]) + bf_lo(r[e]), bf_hi(w[e]) + bf_hi(r[e]));
+                    }
+                    *(u32x4*)(p.y + off) = w;
+                }
+            }
+        }
+    }
+}
+}  // namespace v3
+
 }  // namespace ltxmi
 #ifdef LTXMI_CONV_STAMPS
 extern "C" int ltxmi_debug_set_conv_stamps(void* buf) {
@@ -490,10 +797,31 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     p.tiles_t = (a->T + CD_TT - 1) / CD_TT; p.tiles_y = (a->H + CD_TY - 1) / CD_TY;
     p.tiles_x = (a->W + CD_TX - 1) / CD_TX; p.tiles_n = (a->Cout + 127) / 128;
     const int64_t grid = (int64_t)a->B * p.tiles_t * p.tiles_y * p.tiles_x * p.tiles_n;
+    // whole 128-channel blocks: the four-wave form, two workgroups per CU (algo 3 asks for it, algo 4 for the eight-wave form)
+#ifndef LTXMI_CD_V3
+#define LTXMI_CD_V3 1
+#endif
+    // (from 768 workgroups = 1.5 rounds of the chip's 512 slots; measured: 896 workgroups +5.8 %, 600 -0.6 %, 224 -21 %)
+    if (a->Cout % 128 == 0 && grid < (1ll << 31) && ((LTXMI_CD_V3 && a->algo != 4 && grid >= 768) || a->algo == 3)) {
+#define LTXMI_CDV3_LAUNCH(E)                                                                                   \
+        {                                                                                                      \
+            static unsigned long long lds_done = 0;                                                            \
+            if (const int rc_ = reserve_lds((const void*)v3::conv3d_direct_v3_kernel<E>, v3::SMEM, &lds_done,  \
+                                            "ltxmi_conv3d_ndhwc_bf16"))                                        \
+                return rc_;                                                                                    \
+            hipLaunchKernelGGL(v3::conv3d_direct_v3_kernel<E>, dim3((unsigned)grid), dim3(256), v3::SMEM,      \
+                               stream, p);                                                                     \
+        }
+        if (a->d2s) LTXMI_CDV3_LAUNCH(2)
+        else if (a->add) LTXMI_CDV3_LAUNCH(1)
+        else LTXMI_CDV3_LAUNCH(0)
+#undef LTXMI_CDV3_LAUNCH
+        return check_launch("ltxmi_conv3d_ndhwc_bf16");
+    }
     // one workgroup per CU is resident: below ~half the CUs the implicit GEMM's smaller tiles fill the chip better
-    // (algo = 2 asks for this kernel whatever the grid)
+    // (algo >= 2 asks for the direct convolution whatever the grid)
     constexpr int min_grid = 128;
-    if (grid >= (1ll << 31) || (grid < min_grid && a->algo != 2)) return -1;
+    if (grid >= (1ll << 31) || (grid < min_grid && a->algo < 2)) return -1;
 #define LTXMI_CD_LAUNCH(E)                                                                                     \
     {                                                                                                          \
         static unsigned long long lds_done = 0;                                                                \

@@ -1039,12 +1039,12 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
     }
     LTXMI_REQUIRE((((uintptr_t)a->x | (uintptr_t)a->w) & 15) == 0 && (((uintptr_t)a->y | (uintptr_t)a->bias) & 7) == 0,
                   LTXMI_ERR_UNSUPPORTED, "ltxmi_conv3d_ndhwc_bf16: misaligned pointer");
-    LTXMI_REQUIRE(a->algo >= 0 && a->algo <= 2, LTXMI_ERR_INVALID_ARG, "ltxmi_conv3d_ndhwc_bf16: algo %d not in {0, 1, 2}", a->algo);
+    LTXMI_REQUIRE(a->algo >= 0 && a->algo <= 4, LTXMI_ERR_INVALID_ARG, "ltxmi_conv3d_ndhwc_bf16: algo %d not in {0 .. 4}", a->algo);
     if (a->algo != 1) {
         const int rc = launch_conv3d_direct(a, (hipStream_t)stream);      // narrow stride-1 layers: direct convolution
         if (rc >= 0) return rc;
-        LTXMI_REQUIRE(a->algo != 2, LTXMI_ERR_UNSUPPORTED,
-                      "ltxmi_conv3d_ndhwc_bf16: algo = 2 (direct convolution) does not take this shape");
+        LTXMI_REQUIRE(a->algo < 2, LTXMI_ERR_UNSUPPORTED,
+                      "ltxmi_conv3d_ndhwc_bf16: algo = %d (direct convolution) does not take this shape", a->algo);
     }
     GemmParams p;
     p.A = (const uint16_t*)a->x; p.lda = a->Cin;

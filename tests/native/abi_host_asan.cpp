@@ -158,7 +158,7 @@ int main() {
     expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(zeroed)");
     c.x = p; c.w = p; c.bias = p; c.y = p;
     c.B = 1; c.T = 13; c.H = 32; c.W = 48; c.Cin = 512; c.Cout = 512; c.causal = 1;
-    for (int algo : {0, 1, 2, 9}) {
+    for (int algo : {0, 1, 2, 3, 4, 9}) {
         c.algo = algo;
         expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(no device)");
     }

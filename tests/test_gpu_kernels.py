@@ -744,9 +744,11 @@ def test_gemm_full_size_linearity_ff1_shape():
 @pytest.mark.parametrize("causal,mode,tzero", [(True, "zeros", False), (False, "replicate", False), (False, "zeros", True)])
 @pytest.mark.parametrize("cin,cout,with_add", [(64, 128, False), (128, 256, True), (128, 48, False), (64, 200, True),
                                                (192, 128, True)])      # 1, 2 and 3 chunks of 64 input channels (odd / even tap streams)
-def test_conv3d_direct_path(causal, mode, tzero, cin, cout, with_add):
-    """Shapes the direct (LDS-halo) convolution takes (>= 16384 positions, >= 512 workgroups, Cout % 128 == 0),
-    with partial tiles on every axis (T = 5, H = 36, W = 100 against 2 x 8 x 16 tiles)."""
+@pytest.mark.parametrize("algo", [4, 3])
+def test_conv3d_direct_path(causal, mode, tzero, cin, cout, with_add, algo):
+    """Shapes the direct (LDS-halo) convolution takes, in both of its forms (algo 4: eight waves per workgroup, 64-channel
+    chunks; algo 3: four waves, two workgroups per CU, 32-channel chunks -- where Cout is a multiple of 128, the eight-wave
+    form otherwise), with partial tiles on every axis (T = 5, H = 36, W = 100 against 2 x 8 x 16 tiles)."""
     import torch.nn.functional as F
     from ltxmi import ops
     B, T, H, W = 2, 5, 36, 100
@@ -762,15 +764,17 @@ def test_conv3d_direct_path(causal, mode, tzero, cin, cout, with_add):
     add = rnd(B, cout, T, H, W, seed=113) if with_add else None
     wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
     out = ops.conv3d(ndhwc(x).to(DEV), wp.to(DEV), b.to(DEV), causal, mode == "replicate",
-                     add=ndhwc(add).to(DEV) if with_add else None, time_pad_zeros=tzero)
-    check(ncdhw(out.cpu()), truth + (add.float() if with_add else 0), what=f"direct conv {cin}->{cout}")
+                     add=ndhwc(add).to(DEV) if with_add else None, time_pad_zeros=tzero, algo=algo)
+    check(ncdhw(out.cpu()), truth + (add.float() if with_add else 0), what=f"direct conv {cin}->{cout} algo {algo}")
 
 
 @pytest.mark.parametrize("cin,residual,red", [(256, True, 2), (128, False, 1)])
-def test_conv3d_direct_path_depth_to_space(cin, residual, red):
-    """DepthToSpaceUpsample on the direct-convolution path (Cout/8 a multiple of 128, >= 512 workgroups)."""
-    from ltxmi import autoencoder as ae
+@pytest.mark.parametrize("algo", [4, 3])
+def test_conv3d_direct_path_depth_to_space(cin, residual, red, algo, monkeypatch):
+    """DepthToSpaceUpsample on the direct-convolution path (Cout/8 a multiple of 128), both forms."""
+    from ltxmi import autoencoder as ae, ops
     from oracle import vae as ov
+    monkeypatch.setattr(ops, "CONV_ALGO", algo)
     blk = ae.DepthToSpaceUpsample(3, cin, (2, 2, 2), residual=residual, out_channels_reduction_factor=red,
                                   spatial_padding_mode="replicate").to(BF)
     sd = {k: v.detach().float() for k, v in blk.state_dict().items()}
@@ -794,7 +798,8 @@ def _crop_bands(T, H, W):
 
 @pytest.mark.parametrize("cin,cout,grid,with_add", [(512, 512, (25, 32, 48), True), (1024, 1024, (13, 16, 24), False),
                                                     (1024, 1024, (4, 16, 64), True)])
-def test_conv3d_direct_full_width_bands(cin, cout, grid, with_add):
+@pytest.mark.parametrize("algo", [4, 3])
+def test_conv3d_direct_full_width_bands(cin, cout, grid, with_add, algo):
     """The direct convolution at the channel counts of the timed decoder (Cin 512 / 1024: 8 / 16 chunks of 64 input
     channels per tile) on the bench's own stage grids.  The CPU oracle cannot do 10^11..10^12 FLOP in seconds, but a
     convolution is local: two corner crops of the full-size result are compared with the oracle run on the crops."""
@@ -807,7 +812,7 @@ def test_conv3d_direct_full_width_bands(cin, cout, grid, with_add):
     b = rnd(cout, seed=132)
     add = torch.randn(1, T, H, W, cout, generator=g, device=DEV).to(BF) if with_add else None
     wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous()
-    out = ops.conv3d(x, wp.to(DEV), b.to(DEV), False, True, add=add, algo=2)             # 2 = the direct kernel, or an error
+    out = ops.conv3d(x, wp.to(DEV), b.to(DEV), False, True, add=add, algo=algo)          # the direct kernel in that form, or an error
     assert torch.isfinite(out.float()).all()
     for (ct, cy, cx), (vt, vy, vx) in _crop_bands(T, H, W):
         xc = x[:, ct, cy, cx].permute(0, 4, 1, 2, 3).float().cpu()                       # NCDHW crop

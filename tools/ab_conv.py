@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B several builds of libltxmi.so on the VAE decoder's convolution shapes inside ONE process (alternating launches on
 the same tensors); the first library is the reference of the ratios and of a bit-equality check.
-    python tools/ab_conv.py libA.so libB.so [...]"""
+    python tools/ab_conv.py libA.so libB.so [...]
+An arm may be written lib.so:ALGO (ltxmi_conv3d_args.algo for that arm: 3 / 4 = the direct convolution's four- / eight-wave form)."""
 import ctypes
 import os
 import sys
@@ -21,8 +22,10 @@ def load(path):
 
 
 def main():
-    libs = [load(p) for p in sys.argv[1:]]
-    names = [os.path.basename(p).replace("libltxmi", "").replace(".so", "") or "base" for p in sys.argv[1:]]
+    arms = [a.rsplit(":", 1) if ":" in a else [a, "0"] for a in sys.argv[1:]]
+    libs = [load(p) for p, _ in arms]
+    algos = [int(al) for _, al in arms]
+    names = [(os.path.basename(p).replace("libltxmi", "").replace(".so", "") or "base") + (f":{al}" if al != "0" else "") for p, al in arms]
     # (T, H, W, Cin, Cout, depth-to-space, skip add): the layers of a 768x512x97 decode, with their share of it
     shapes = [(97, 128, 192, 128, 128, 0, 1, "128->128 +skip (x4: 8.0 ms)"), (49, 64, 96, 256, 256, 0, 0, "256->256 (x4: 3.8 ms)"),
               (49, 64, 96, 256, 1024, 1, 0, "256->1024 d2s (4.1 ms)"), (25, 32, 48, 512, 512, 0, 1, "512->512 +skip (x4: 2.2 ms)"),
@@ -48,6 +51,7 @@ def main():
         ref = None
         for rep in range(6):
             for i, lib in enumerate(libs):
+                a.algo = algos[i]
                 for _ in range(2):
                     assert lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), stream) == 0
                 if rep == 0:
