@@ -668,6 +668,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
 
     // ---- in front of the stream: planes 0 and 1 of the first chunk's halo, the weights of its taps 0 and 1
     const int nchunks = p.Cin >> 5;
+    // Two workgroups share a CU and each SIMD has one wave of either.  With equal priorities the two waves of a SIMD drift into
+    // phase (both in their MFMAs, at half rate each, then both in everything else with the pipe idle); a static priority for one of
+    // them keeps them apart.  Workgroups are dealt to the CUs' first slots, then to their second slots, 256 at a time, so bit 8
+    // of the workgroup number tells a CU's two residents apart (exactly in the first round, mostly afterwards): +1 % over a
+    // decode's convolutions, +4.6 % on the 896-workgroup layer; by parity of the number instead: nothing.
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
     __syncthreads();                                             // the tables are complete
 #pragma unroll
     for (int k = 0; k < Q_PLANE1 / 4; ++k) {

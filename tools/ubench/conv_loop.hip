@@ -18,12 +18,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((address_space(1))) void* glb_ptr;
 
-template <int V>
-__global__ __launch_bounds__(512) void k(const uint32_t* __restrict__ rnd, float* out, unsigned long long* cyc, int iters, int salt) {
+template <int V, int THREADS>
+__global__ __launch_bounds__(THREADS) void k(const uint32_t* __restrict__ rnd, float* out, unsigned long long* cyc, int iters, int salt) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-    for (int i = tid; i < 36864; i += 512) ((uint32_t*)lds)[i] = rnd[i & 8191] & 0x3f803f80u;    // 144 KB of small bf16 values
+    for (int i = tid; i < (THREADS == 512 ? 36864 : 19200); i += THREADS) ((uint32_t*)lds)[i] = rnd[i & 8191] & 0x3f803f80u;   // small bf16 values
     __syncthreads();
     const int frow = lane & 15, fchunk = lane >> 4;
     bf16x8 af[2][4][2], bfr[2][4][2];
@@ -37,17 +37,18 @@ __global__ __launch_bounds__(512) void k(const uint32_t* __restrict__ rnd, float
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int b_off[4];
-    for (int j = 0; j < 4; ++j) b_off[j] = 92160 + (wn * 64 + j * 16 + frow) * 128 + ((fchunk ^ (frow & 7)) << 4);
+    constexpr int WOFF = THREADS == 512 ? 92160 : 32768;       // (the four-wave form's LDS is half the size)
+    for (int j = 0; j < 4; ++j) b_off[j] = WOFF + (wn * 64 + j * 16 + frow) * 128 + ((fchunk ^ (frow & 7)) << 4);
     int n_off = salt, ctl = salt;
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     auto body = [&](auto s_tag, auto n_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(s_tag)::value, N = decltype(n_tag)::value;
         if (V & 32) {
-            __builtin_amdgcn_global_load_lds((glb_ptr)(rnd + (wave * 2) * 256 + lane * 4), (lds_ptr)(lds + 92160 + 49152 + wave * 2048), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr)(rnd + (wave * 2 + 1) * 256 + lane * 4), (lds_ptr)(lds + 92160 + 49152 + wave * 2048 + 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(rnd + (wave * 2) * 256 + lane * 4), (lds_ptr)(lds + WOFF + 32768 + wave * 2048), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(rnd + (wave * 2 + 1) * 256 + lane * 4), (lds_ptr)(lds + WOFF + 32768 + wave * 2048 + 1024), 16, 0, 0);
         }
-        const char* ws = lds + ((n_off & 1) << 14);
+        const char* ws = lds + ((n_off & 1) << 13);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -59,9 +60,9 @@ __global__ __launch_bounds__(512) void k(const uint32_t* __restrict__ rnd, float
                 int row;
                 if (V & 4) {
                     const int blk = wm * 4 + i;
-                    row = ((blk >> 3) * 10 + (blk & 7)) * 18 + (n_off & 255) + frow;
+                    row = (((blk >> 3) * 10 + (blk & 7)) * 18 + (n_off & 255) + frow) & 255;
                 } else {
-                    row = (wm * 4 + i) * 18 + frow;
+                    row = ((wm * 4 + i) * 18 + frow) & 255;
                 }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -95,29 +96,30 @@ __global__ __launch_bounds__(512) void k(const uint32_t* __restrict__ rnd, float
     float sum = (float)ctl;
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    out[blockIdx.x * 512 + tid] = sum;
-    if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+    out[blockIdx.x * THREADS + tid] = sum;
+    if (lane == 0) cyc[blockIdx.x * (THREADS / 64) + wave] = t1 - t0;
 }
 
-template <int V>
+template <int V, int THREADS = 512>
 static void run(const uint32_t* rnd, float* out, unsigned long long* cyc, const char* what) {
-    const int iters = 2048, grid = 256;
-    hipFuncSetAttribute((const void*)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    const int iters = 2048, grid = THREADS == 512 ? 256 : 512;      // one 8-wave workgroup or two 4-wave workgroups per CU
+    const int smem = THREADS == 512 ? 147456 : 76800;
+    hipFuncSetAttribute((const void*)k<V, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k<V>, dim3(grid), dim3(512), 147456, 0, rnd, out, cyc, iters, 5);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k<V, THREADS>), dim3(grid), dim3(THREADS), smem, 0, rnd, out, cyc, iters, 5);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<V>, dim3(grid), dim3(512), 147456, 0, rnd, out, cyc, iters, 5);
+    hipLaunchKernelGGL((k<V, THREADS>), dim3(grid), dim3(THREADS), smem, 0, rnd, out, cyc, iters, 5);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(grid * 8);
+    std::vector<unsigned long long> h(grid * (THREADS / 64));
     hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     const double cpi = (double)h[h.size() / 2] / iters;
-    const double flop = 2.0 * 64 * 64 * 64 * 8 * grid * (double)iters;      // per wave and iteration: 64 x 64 x 64
-    printf("V=%2d %-58s: %7.1f cycles / iteration (matrix pipe: 1024 per SIMD pair)  %6.3f ms  %6.0f TFLOP/s\n", V, what, cpi, ms, flop / ms / 1e9);
+    const double flop = 2.0 * 64 * 64 * 64 * (THREADS / 64) * grid * (double)iters;      // per wave and iteration: 64 x 64 x 64
+    printf("V=%2d x%d %-58s: %7.1f cycles / iteration (matrix pipe: 1024 per SIMD pair)  %6.3f ms  %6.0f TFLOP/s\n", V, THREADS / 64, what, cpi, ms, flop / ms / 1e9);
 }
 
 int main() {
@@ -125,7 +127,7 @@ int main() {
     std::vector<uint32_t> h(8192 * 4);
     srand(1);
     for (auto& x : h) x = (uint32_t)rand() * 2654435761u;
-    hipMalloc(&rnd, h.size() * 4); hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8 * 8);
+    hipMalloc(&rnd, h.size() * 4); hipMalloc(&out, 512 * 512 * 4); hipMalloc(&cyc, 512 * 8 * 8);
     hipMemcpy(rnd, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     run<0>(rnd, out, cyc, "bare MFMAs");
     run<1>(rnd, out, cyc, "+ sched_barrier per block");
@@ -138,5 +140,11 @@ int main() {
     run<17>(rnd, out, cyc, "bare MFMAs + scalar blob");
     run<33>(rnd, out, cyc, "bare MFMAs + LDS-DMA");
     run<11>(rnd, out, cyc, "MFMAs + reads + s_barrier");
+    // the same with FOUR waves per workgroup and two workgroups per CU (the two waves of a SIMD belong to different workgroups)
+    run<0, 256>(rnd, out, cyc, "bare MFMAs");
+    run<15, 256>(rnd, out, cyc, "+ reads, addresses, s_barrier");
+    run<31, 256>(rnd, out, cyc, "+ ~140 scalar instructions behind block 2");
+    run<63, 256>(rnd, out, cyc, "+ two LDS-DMA pieces + vmcnt(0)");
+    run<17, 256>(rnd, out, cyc, "bare MFMAs + scalar blob");
     return 0;
 }
