@@ -340,7 +340,7 @@ def time_vae(device, iters, grid=GRID, z_tile=0):
         flop = 54.0 * 128 * 128 * pos3
         byts = (128 + 128) * pos3 * 2 + 27 * 128 * 128 * 2
         out["roofline_conv"] = {
-            "kernel": f"conv3d_direct_kernel (CausalConv3d 128 -> 128 at {pos3} positions, the full-resolution stage)",
+            "kernel": f"conv3d_direct_v3_kernel (CausalConv3d 128 -> 128 at {pos3} positions, the full-resolution stage)",
             "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), "launch_ms": round(ms, 4), "launches_timed": len(conv_ms),
             "algorithmic_flop_per_launch": flop, "algorithmic_bytes_per_launch": byts,
