@@ -6,6 +6,12 @@ import fails loudly -- there is no PyTorch/CPU fallback.
 import ctypes
 import os
 
+# torch FIRST: its wheel ships a HIP runtime of its own (torch/lib/libamdhip64.so).  Loaded before torch, libltxmi.so pulls in the
+# system's /opt/rocm runtime instead, the process then holds two HIP runtimes, and the library's calls (hipGetDevice, launches on
+# torch's streams) go to the one torch never initialised: "cannot query the current device" on the first kernel.  With torch's
+# runtime already in the process the library's DT_NEEDED entry resolves to it.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LTXMI_LIB: tuning knob only (A/B runs of two builds of the SAME library); never a fallback path
 LIB_PATH = os.environ.get("LTXMI_LIB") or os.path.join(_HERE, "libltxmi.so")
