@@ -210,11 +210,46 @@ def time_attention(device, n_tok, iters, B=1, heads=H, dh=DH, lk=None):
     ms = pct(ts, 0.5)
     flops = 4.0 * B * n_tok * k.shape[1] * heads * dh       # QK^T + PV
     tf = flops / ms / 1e9
-    return {"tokens": n_tok, "keys": k.shape[1], "batch": B, "heads": heads, "head_dim": dh, "ms": round(ms, 3),
-            "ms_p10": round(pct(ts, 0.1), 3), "ms_p90": round(pct(ts, 0.9), 3), "iters": iters,
-            "tflops": round(tf, 1), "qk_frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-            "algorithmic_bytes": 2 * B * heads * dh * (2 * n_tok + 2 * k.shape[1]),
-            "note": "QK^T and PV run at the same rate: fraction = (4 Lq Lk H dh / t) / peak = (2 Lq Lk H dh / (t/2)) / peak"}
+    res = {"tokens": n_tok, "keys": k.shape[1], "batch": B, "heads": heads, "head_dim": dh, "ms": round(ms, 3),
+           "ms_p10": round(pct(ts, 0.1), 3), "ms_p90": round(pct(ts, 0.9), 3), "iters": iters,
+           "tflops": round(tf, 1), "qk_frac_of_mfma_peak": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+           "algorithmic_bytes": 2 * B * heads * dh * (2 * n_tok + 2 * k.shape[1]),
+           "note": "QK^T and PV run at the same rate: fraction = (4 Lq Lk H dh / t) / peak = (2 Lq Lk H dh / (t/2)) / peak"}
+    D = heads * dh
+    if lk is None and ops.attention_fuses_qnorm(B, heads, n_tok, n_tok, dh):
+        # the same launch as Transformer3DModel.forward makes it at this shape: q is the raw projection output and the kernel
+        # applies q_norm (row factor), its weight and RoPE while loading it (then softmax_scale * log2(e) goes into q before
+        # its rounding and the loop has no multiply per score).  Checked against the two-pass form (q's pass, then the launch
+        # timed above) on a band of rows.
+        wq = (1.0 + 0.1 * torch.randn(D, generator=g, device=device)).to(torch.bfloat16)
+        ang = torch.rand(n_tok, D // 2, generator=g, device=device) * 6.28
+        cos, sin = (f(ang).repeat_interleave(2, dim=-1).to(torch.bfloat16) for f in (torch.cos, torch.sin))
+        del ang
+        q2 = q.reshape(B * n_tok, D)
+        rstd = torch.rsqrt(q2.float().pow(2).mean(-1) + 1e-6).contiguous()
+        out_f = torch.empty_like(out)
+        ops.attention(q, k, v, out=out_f, q_norm=(rstd, wq, 1e-6), rope=(cos, sin, n_tok))
+        band = slice(n_tok - 256, n_tok)
+        qb = q[:, band].clone()
+        ops.rmsnorm_rope_(qb.view(-1, D), wq, 1e-6, cos[band], sin[band], 256)
+        two_pass = ops.attention(qb, k, v)
+        err = float((out_f[:, band].float() - two_pass.float()).norm() / two_pass.float().norm())
+        assert err < 6e-3, f"attention N={n_tok}: q on load differs from the two-pass form by {err:.3e}"
+        ts = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.attention(q, k, v, out=out_f, q_norm=(rstd, wq, 1e-6), rope=(cos, sin, n_tok))
+            e1.record()
+            ts.append((e0, e1))
+        torch.cuda.synchronize()
+        ms_f = pct([a.elapsed_time(b) for a, b in ts], 0.5)
+        res["as_the_model_launches_it"] = {
+            "ms": round(ms_f, 3), "tflops": round(flops / ms_f / 1e9, 1),
+            "qk_frac_of_mfma_peak": round(flops / ms_f / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "note": "q_norm + weight + RoPE applied to q on load (attention.py:1040-1055 of the reference fused into the launch, "
+                    "as ltxmi.Transformer3DModel does at this shape); same FLOP count, the q pass it replaces not credited"}
+    return res
 
 
 def make_vae(device, grid=GRID, z_tile=0):

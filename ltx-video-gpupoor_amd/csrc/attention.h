@@ -24,7 +24,7 @@ struct AttnParams {
     // return all-to-all's send buffer [P dst][B][N / P][H dh]); 0 = one segment
     int o_seg; int64_t o_sseg;
 
-    __device__ __forceinline__ bool q_on_load() const { return q_ss != nullptr || q_rstd != nullptr; }
+    __host__ __device__ __forceinline__ bool q_on_load() const { return q_ss != nullptr || q_rstd != nullptr; }
     // q's RMSNorm factor of row `row` of batch b (HD = H * head_dim, the normalised width)
     __device__ __forceinline__ float q_row_rstd(int b, int row, int HD) const {
         if (q_rstd) return q_rstd[(int64_t)b * q_rstd_sb + (int64_t)row * q_rstd_sl];

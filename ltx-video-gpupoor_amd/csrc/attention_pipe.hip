@@ -11,10 +11,12 @@
 //     runs the other block's products:
 //         segment 1:  softmax A(t)      ||  row sums B(t-1), QK^T B(t),   PV B(t-1)
 //         segment 2:  softmax B(t)      ||  row sums A(t),   QK^T A(t+1), PV A(t)
-//     At head_dim 64 the VALU (exp2 + fma + cvt per score) needs slightly MORE issue cycles than
-//     the MFMAs of the same scores need pipe cycles, so every MFMA is issued with five VALU
-//     instructions behind it and neither pipe ever waits for a whole phase of the other.  The
-//     interleave is written out in the source, chunk by chunk, and pinned with sched_barrier.
+//     At head_dim 64 the textbook softmax (exp2 + fma + cvt per score, tile maxima) needs MORE VALU issue
+//     cycles than the MFMAs of the same scores need pipe cycles, so (a) every MFMA is issued with its share
+//     of the VALU work behind it and neither pipe ever waits for a whole phase of the other -- the
+//     interleave is written out in the source, chunk by chunk, and pinned with sched_barrier -- and
+//     (b) the normal run does no VALU work per score beyond exp2 + cvt: q arrives scaled by
+//     softmax_scale * log2(e), and P = 2^s is taken against the reference 0 for every row (see the kernel).
 //   * K / V tiles go HBM -> LDS by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction) into
 //     two rings of four 8-KiB slots, K three tiles ahead and V two, behind a counted vmcnt: no
 //     staging registers, no ds_write, and no VMEM/LDS-store issue slots taken from the softmax.
@@ -76,8 +78,10 @@ struct Lane {
 // scores against the K slot `ks`.
 // hook(j) runs once per chunk j, right behind the chunk's MFMA: the kernel uses it to issue its LDS-DMA pieces one at a
 // time in the shadow of an MFMA instead of as a burst of four behind the barrier
-// STEADY: X's reference maximum is final (see the kernel): no tile maximum, no rescale.
-template <bool STEADY, typename Hook>
+// QSCALED: the scores arrive in bits (q was scaled by c = softmax_scale * log2(e) before its rounding to bf16, see the
+// kernel); otherwise they are raw and c is applied here.
+// STEADY: P = 2^(c s) against the fixed reference 0 (see the kernel): no tile maximum, no rescale, no subtraction.
+template <bool STEADY, bool QSCALED, typename Hook>
 __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const char* vs, const Lane& L,
                                         const bf16x8& ones, float c, int key0, int Lk, Stamps& st, int st0, Hook&& hook) {
     // ---- head: K fragments of the whole slot (8 x ds_read_b128), Y's row sums, X's row max
@@ -118,7 +122,7 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
         // the O-wide rescale is a real wave-uniform branch
         if (__any(m_new != X.m)) {
             asm volatile("; rescale branch (kept a real branch: not if-converted)" ::: "memory");
-            const float alpha = fast_exp2((X.m - m_new) * c);
+            const float alpha = fast_exp2(QSCALED ? X.m - m_new : (X.m - m_new) * c);
             X.l[0] *= alpha;
             X.l[1] *= __shfl(alpha, (L.lane + 16) & 63, 64);
 #pragma unroll
@@ -128,12 +132,12 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
             X.m = m_new;
         }
     }
-    const float nmoff = -X.m * c;
+    const float nmoff = STEADY ? 0.f : QSCALED ? -X.m : -X.m * c;
     __builtin_amdgcn_sched_barrier(0);
     STAMP(st0);
 
     // ---- 16 chunks: one 32x32x16 MFMA, the LDS reads of a later MFMA, and two scores' worth of
-    // softmax (2 fma, 2 exp2, 1 cvt_pk) each
+    // softmax (2 exp2, 1 cvt_pk; + 2 v_mul for raw scores; the exact form: + 2 v_sub / v_fma) each
     bf16x8 vf[8];
     float pp0 = 0.f, pp1 = 0.f;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -160,8 +164,9 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
         // softmax of two scores; the pair is packed one chunk later (a v_cvt_pk right behind the v_exp
         // it reads costs an s_nop: transcendental -> VALU hazard)
         const int kb = j >> 3, e0 = 2 * (j & 7);
-        const float p0 = fast_exp2(__builtin_fmaf(X.s[kb][e0], c, nmoff));
-        const float p1 = fast_exp2(__builtin_fmaf(X.s[kb][e0 + 1], c, nmoff));
+        auto bits = [&](float sc) { return QSCALED ? (STEADY ? sc : sc + nmoff) : (STEADY ? sc * c : __builtin_fmaf(sc, c, nmoff)); };
+        const float p0 = fast_exp2(bits(X.s[kb][e0]));
+        const float p1 = fast_exp2(bits(X.s[kb][e0 + 1]));
         if (j > 0) {
             const int jp = j - 1, kbp = jp >> 3, ep = 2 * (jp & 7);
             // (the empty asm pins the conversion to this chunk: instruction selection otherwise gathers
@@ -181,7 +186,10 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
 // One work item = one (batch, head, 256-row query tile).  REDO = false: the normal run (exact form for the first two key
 // tiles, steady form for the rest, then the check for outgrown references); returns true -- WITHOUT having stored anything --
 // when the workgroup has to go through the item again.  REDO = true: exact form throughout, always stores.
-template <bool REDO>
+// QSCALED = q is produced on load (the fused K1 below): softmax_scale * log2(e) goes into it before its one rounding to bf16
+// and the scores leave the matrix pipe in bits.  A q that arrives as bf16 is left as it is (scaling it would round it a second
+// time, an error proportional to the score: visible once logits reach tens of nats) and its scores take one v_mul each.
+template <bool REDO, bool QSCALED>
 __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int tid, char* smem) {
     char* kring = smem;
     char* vring = smem + RING * TILE_BYTES;
@@ -298,12 +306,13 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
 #pragma unroll
         for (int e = 0; e < 8; ++e) ones[e] = on ? (__bf16)1.0f : (__bf16)0.0f;
     }
+    const float c = p.scale_log2e;
     auto init = [&](Blk& X, int blk) {
         const int row = qt * Q_PER_WG + wave * 64 + 32 * blk + L.r;
         const int q_ld = row < p.Lq ? row : p.Lq - 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) X.q[s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * L.hh);
-        if (p.q_on_load()) {
+        if (QSCALED) {                     // == p.q_on_load(): the launcher picks the instance by it
             // fused K1: q is the raw projection output.  q_norm (RMSNorm over all H * dh channels, attention.py:478-479,
             // 1040-1041) from the row's factor (finalised per row by k's pass, or the projection GEMM's partial sums of
             // squares), x weight, then the interleaved-pair RoPE on the flat channel axis (:960-975, 1053-1055) -- the
@@ -327,8 +336,9 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
                         o[e + 1] = r1;
                     }
                 }
+                // (x softmax_scale * log2(e) before the one rounding: the scores leave the matrix pipe in bits)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) X.q[s][e] = (__bf16)o[e];
+                for (int e = 0; e < 8; ++e) X.q[s][e] = (__bf16)(QSCALED ? o[e] * c : o[e]);
             }
         }
         X.m = -INFINITY;
@@ -340,13 +350,15 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
 #pragma unroll
             for (int e = 0; e < 16; ++e) { X.o[d][e] = 0.f; X.s[d][e] = 0.f; }
     };
-    // The loop exists in two forms.  EXACT: the textbook online softmax -- tile maximum, running maximum, rescale of O / l
-    // whenever a row's maximum grows.  STEADY: every row keeps the reference it has (P = 2^((s - m) c) may exceed 1, which
-    // floating point does not mind) -- no tile maximum (14 VALU instructions per block and tile on a loop that is
-    // VALU-issue-bound), no branch.  The first two key tiles run EXACT, while the maxima are still settling; the rest run
-    // STEADY.  A score ~100 bits (69 nats) or more above everything in its row's first 128 keys would overflow against the
-    // fixed reference (or make 1 / l denormal): that leaves a row sum or accumulator of magnitude >= 2^100, which the
-    // workgroup checks for after its last key tile -- and then redoes the item with EXACT throughout (attempt 1).
+    // The loop exists in two forms.  STEADY, the normal run: P = 2^s with every row's reference at 0 -- softmax is invariant
+    // under the choice of reference, and fp32 / bf16 carry the same RELATIVE precision at every magnitude, so as long as
+    // nothing leaves the exponent range the result is the textbook one to rounding.  No tile maximum, no running maximum,
+    // no subtraction, no rescale branch: per score the VALU issues an exp2 and half a cvt_pk, on a loop whose VALU port was
+    // fuller than its matrix pipe.  What can go wrong is range: a score above ~ +100 bits (69 nats) overflows a row sum /
+    // accumulator, a row whose scores ALL lie below ~ -100 bits loses its sum to underflow (1 / l overflows).  Both leave a
+    // row sum or accumulator outside [2^-100, 2^100), which the workgroup checks for after its last key tile -- and then
+    // redoes the item in the EXACT form (REDO): the textbook online softmax, tile maximum, running maximum, rescale of O / l
+    // whenever a row's maximum grows.
     volatile int* redo_flag = (volatile int*)(smem + SMEM);           // one word behind the rings
     if (!REDO && tid == 0) *redo_flag = 0;
     const bool wave_idle = qt * Q_PER_WG + wave * 64 >= p.Lq;
@@ -376,7 +388,7 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
     { unsigned long long t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory"); st.prev = t0_; }
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0_)::"memory");
 #endif
-    const int t_exact = REDO ? nt : (nt < 2 ? nt : 2);
+    const int t_exact = REDO ? nt : 0;
     if (wave_idle) {
         for (int t = 0; t < nt; ++t) {
             __builtin_amdgcn_s_barrier();
@@ -394,7 +406,6 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
                 A.s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, A.q[s], A.s[kb2], 0, 0, 0);
             }
 
-        const float c = p.scale_log2e;
         using exact_form = std::integral_constant<bool, false>;
         using steady_form = std::integral_constant<bool, true>;
         auto iteration = [&](int t, auto steady_tag) {
@@ -406,9 +417,9 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
             // this iteration's four LDS-DMA pieces -- K(t+3) into the slot K(t-1) left at this barrier, V(t+2) into V(t-2)'s --
             // go out one at a time behind an MFMA (chunks 3 and 11 of each segment), in this order (the counted wait below
             // relies on it): a burst of four behind the barrier cost ~200 cycles per iteration with the wave issuing nothing else
-            segment<STEADY>(A, Bk, kring + (t & 3) * TILE_BYTES, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2,
+            segment<STEADY, QSCALED>(A, Bk, kring + (t & 3) * TILE_BYTES, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2,
                           [&](int j) { if (j == 3) dma_k1(t + 3, 0); else if (j == 11) dma_k1(t + 3, 1); });
-            segment<STEADY>(Bk, A, kring + ((t + 1) & 3) * TILE_BYTES, vring + (t & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 4,
+            segment<STEADY, QSCALED>(Bk, A, kring + ((t + 1) & 3) * TILE_BYTES, vring + (t & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 4,
                           [&](int j) { if (j == 3) dma_v1(t + 2, 0); else if (j == 11) dma_v1(t + 2, 1); });
             // everything issued before this iteration's four pieces has landed: K(t+2), V(t+1)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -454,13 +465,18 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
     bool outgrown = false;
     if (t_exact < nt && !wave_idle) {
         // a row sum or an accumulator of magnitude >= 2^100 (or inf / NaN: the test is on the exponent bits, the file is
-        // built with -fno-honor-nans) = a score outgrew its row's fixed reference.  Not only overflow: 1 / l for l > 2^126 is
-        // a denormal and flushes to zero; a legitimate l is at most (keys) x 2^(a few bits).
-        constexpr uint32_t OUTGROWN_EXP = (127u + 100u) << 23;
+        // built with -fno-honor-nans) = a score too large for the fixed reference (not only overflow: 1 / l for l > 2^126 is
+        // a denormal and flushes to zero); a row sum below 2^-100 (or 0) = a row whose scores all underflowed.
+        constexpr uint32_t OUTGROWN_EXP = (127u + 100u) << 23, VANISHED_EXP = (127u - 100u) << 23;
         uint32_t worst = 0;
         auto scan = [&](const Blk& X) {
             worst |= (uint32_t)((__float_as_uint(X.l[0]) & 0x7f800000u) >= OUTGROWN_EXP);
             worst |= (uint32_t)((__float_as_uint(X.l[1]) & 0x7f800000u) >= OUTGROWN_EXP);
+            // (the row sums live in lanes 0..15, registers 0 / 1; a sum of 0 has exponent bits 0)
+            if (L.lane < 16) {
+                worst |= (uint32_t)((__float_as_uint(X.l[0]) & 0x7f800000u) < VANISHED_EXP);
+                worst |= (uint32_t)((__float_as_uint(X.l[1]) & 0x7f800000u) < VANISHED_EXP);
+            }
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -509,16 +525,16 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
     return false;
 }
 
-template <int OCC>
+template <int OCC, bool QSCALED>
 __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    if (!attn_pipe_item<false>(p, tid, smem)) return;
+    if (!attn_pipe_item<false, QSCALED>(p, tid, smem)) return;
     // (rare) the item again, exact form throughout.  The thread id is laundered through an empty asm so that nothing the first
     // run derived from it is kept alive -- i.e. spilled -- across its loops for this path's sake: everything is recomputed.
     int tid2 = tid;
     asm volatile("" : "+v"(tid2));
-    attn_pipe_item<true>(p, tid2, smem);
+    attn_pipe_item<true, QSCALED>(p, tid2, smem);
 }
 
 }  // namespace pipe
@@ -546,9 +562,10 @@ bool attn_pipe_takes(int B, int H, int Lq, int Lk, int head_dim, bool has_bias) 
 int launch_attn_pipe(AttnParams p, hipStream_t stream) {
     // the buffer descriptors address a (batch, head)'s K / V rows with 32-bit byte offsets
     if (!attn_pipe_span_ok(p.Lk, p.k_sl, p.v_sl, pipe::DH)) return -1;
-    auto kern = pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC>;
-    static unsigned long long lds_done = 0;
-    if (const int rc = reserve_lds((const void*)kern, pipe::SMEM + 16, &lds_done, "ltxmi_attention_fwd_bf16")) return rc;
+    const bool qscaled = p.q_on_load();
+    auto kern = qscaled ? pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC, true> : pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC, false>;
+    static unsigned long long lds_done[2] = {0, 0};
+    if (const int rc = reserve_lds((const void*)kern, pipe::SMEM + 16, &lds_done[qscaled], "ltxmi_attention_fwd_bf16")) return rc;
     p.q_tiles = (p.Lq + pipe::Q_PER_WG - 1) / pipe::Q_PER_WG;
     const int64_t grid = (int64_t)p.B * p.H * p.q_tiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pipe::SMEM + 16, stream, p);
