@@ -73,6 +73,11 @@ struct Lane {
     int v_rd;        // byte offset of this lane's transposed-read address inside a V slot
 };
 
+// K fragment j of a slot: key block j >> 2 (32 keys), k-step j & 3 (16 head-dim columns)
+__device__ __forceinline__ bf16x8 k_fragment(const char* slot, const Lane& L, int j) {
+    return *(const bf16x8*)(slot + L.k_rd[j >> 2] + (((2 * (j & 3) + L.hh) ^ L.k_sw0) << 4));
+}
+
 // One segment: VALU = softmax of X's pending scores (X.s -> X.pf, X.m, rescale of X.o / X.l);
 // matrix pipe = Y's row sums and PV with Y's pending P against the V slot `vs`, and Y's next
 // scores against the K slot `ks`.
@@ -82,13 +87,11 @@ struct Lane {
 // kernel); otherwise they are raw and c is applied here.
 // STEADY: P = 2^(c s) against the fixed reference 0 (see the kernel): no tile maximum, no rescale, no subtraction.
 template <bool STEADY, bool QSCALED, typename Hook>
-__device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const char* vs, const Lane& L,
+__device__ __forceinline__ void segment(Blk& X, Blk& Y, bf16x8 (&kf)[8], const char* ks_next, const char* vs, const Lane& L,
                                         const bf16x8& ones, float c, int key0, int Lk, Stamps& st, int st0, Hook&& hook) {
-    // ---- head: K fragments of the whole slot (8 x ds_read_b128), Y's row sums, X's row max
-    bf16x8 kf[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        kf[j] = *(const bf16x8*)(ks + L.k_rd[j >> 2] + (((2 * (j & 3) + L.hh) ^ L.k_sw0) << 4));
+    // ---- head: Y's row sums, X's row max.  kf = the K fragments of this segment's slot, requested one per chunk by the
+    // second half of the PREVIOUS segment (whose K registers are free from its chunk 8 on); this segment does the same for the
+    // next one's slot `ks_next` -- a whole-slot burst of 8 ds_read_b128 at the head had every wave wait out the LDS latency here
 #pragma unroll
     for (int sp = 0; sp < 4; ++sp) Y.l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, Y.pf[sp]), Y.l, 0, 0, 0);
 
@@ -159,6 +162,7 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, const char* ks, const ch
         } else {
             const int jj = j - 8, sp = jj >> 1, d = jj & 1;
             Y.o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jj], __builtin_bit_cast(bf16x8, Y.pf[sp]), Y.o[d], 0, 0, 0);
+            kf[jj] = k_fragment(ks_next, L, jj);
         }
         hook(j);
         // softmax of two scores; the pair is packed one chunk later (a v_cvt_pk right behind the v_exp
@@ -362,6 +366,9 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
     volatile int* redo_flag = (volatile int*)(smem + SMEM);           // one word behind the rings
     if (!REDO && tid == 0) *redo_flag = 0;
     const bool wave_idle = qt * Q_PER_WG + wave * 64 >= p.Lq;
+    // the two workgroups of a CU otherwise fall into step (both in their segment heads / at their barriers together): a static
+    // priority for every other dispatch round breaks the symmetry (+0.9 % at the workload shape, nothing at long sequences)
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
     Stamps st;
 #ifdef LTXMI_ATTN_STAMPS
     unsigned long long rt0_ = 0;
@@ -397,14 +404,12 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
     } else {
-        // S_A(0)
+        // S_A(0); the fragments of K slot 0 stay in kf for segment 1 of iteration 0 (S_B(0))
+        bf16x8 kf[8];
 #pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
+        for (int j = 0; j < 8; ++j) kf[j] = k_fragment(kring, L, j);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 kf = *(const bf16x8*)(kring + L.k_rd[kb2] + (((2 * s + L.hh) ^ L.k_sw0) << 4));
-                A.s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, A.q[s], A.s[kb2], 0, 0, 0);
-            }
+        for (int j = 0; j < 8; ++j) A.s[j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], A.q[j & 3], A.s[j >> 2], 0, 0, 0);
 
         using exact_form = std::integral_constant<bool, false>;
         using steady_form = std::integral_constant<bool, true>;
@@ -417,9 +422,9 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
             // this iteration's four LDS-DMA pieces -- K(t+3) into the slot K(t-1) left at this barrier, V(t+2) into V(t-2)'s --
             // go out one at a time behind an MFMA (chunks 3 and 11 of each segment), in this order (the counted wait below
             // relies on it): a burst of four behind the barrier cost ~200 cycles per iteration with the wave issuing nothing else
-            segment<STEADY, QSCALED>(A, Bk, kring + (t & 3) * TILE_BYTES, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2,
+            segment<STEADY, QSCALED>(A, Bk, kf, kring + ((t + 1) & 3) * TILE_BYTES, vring + ((t + 3) & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 2,
                           [&](int j) { if (j == 3) dma_k1(t + 3, 0); else if (j == 11) dma_k1(t + 3, 1); });
-            segment<STEADY, QSCALED>(Bk, A, kring + ((t + 1) & 3) * TILE_BYTES, vring + (t & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 4,
+            segment<STEADY, QSCALED>(Bk, A, kf, kring + ((t + 1) & 3) * TILE_BYTES, vring + (t & 3) * TILE_BYTES, L, ones, c, t * KV_TILE, p.Lk, st, 4,
                           [&](int j) { if (j == 3) dma_v1(t + 2, 0); else if (j == 11) dma_v1(t + 2, 1); });
             // everything issued before this iteration's four pieces has landed: K(t+2), V(t+1)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");

@@ -2,6 +2,7 @@
 """A/B builds of libltxmi.so on the self-attention shapes inside ONE process (alternating launches on the
 same tensors: clocks / box / data are common to all arms), plus a cross-check of every arm against arm 0.
     python tools/ab_attn.py libA.so libB.so [libC.so ...]
+AB_Q_ON_LOAD=1: launch as the DiT does (q's row factor and weight applied on load: the head_dim-64 kernel's QSCALED instance).
 """
 import ctypes
 import os
@@ -36,7 +37,7 @@ def main():
     for (B, H, N, dh, it) in shapes:
         qkv = torch.randn(B, N, 3, H, dh, device="cuda").to(torch.bfloat16)
         outs = [torch.empty(B, N, H, dh, device="cuda", dtype=torch.bfloat16) for _ in libs]
-        args = []
+        args, keep = [], []
         for o in outs:
             a = _lib.AttnArgs()
             q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
@@ -46,6 +47,10 @@ def main():
             a.o, a.o_stride_b, a.o_stride_l = o.data_ptr(), o.stride(0), o.stride(1)
             a.key_bias, a.bias_stride_b = None, 0
             a.B, a.H, a.Lq, a.Lk, a.head_dim, a.softmax_scale = B, H, N, N, dh, dh ** -0.5
+            if os.environ.get("AB_Q_ON_LOAD") == "1":      # the DiT's launch form: q finished on load (row factor x weight)
+                keep.append((torch.ones(B * N, device="cuda", dtype=torch.float32), torch.ones(H * dh, device="cuda", dtype=torch.bfloat16)))
+                a.q_rstd, a.q_rstd_stride_b, a.q_rstd_stride_l = keep[-1][0].data_ptr(), N, 1
+                a.q_norm_weight, a.q_norm_eps = keep[-1][1].data_ptr(), 1e-6
             args.append(a)
         times = [[] for _ in libs]
         for rep in range(6):

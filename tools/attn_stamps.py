@@ -32,6 +32,12 @@ a.v, a.v_stride_b, a.v_stride_l = v.data_ptr(), v.stride(0), v.stride(1)
 a.o, a.o_stride_b, a.o_stride_l = o.data_ptr(), o.stride(0), o.stride(1)
 a.key_bias, a.bias_stride_b = None, 0
 a.B, a.H, a.Lq, a.Lk, a.head_dim, a.softmax_scale = B, H, N, N, dh, dh ** -0.5
+if os.environ.get("STAMPS_PLAIN_Q") != "1":
+    # the launch form of the DiT: q finished on load (row factor + weight; no RoPE tables here), scale folded into q
+    rstd = torch.ones(B * N, device="cuda", dtype=torch.float32)
+    wq = torch.ones(H * dh, device="cuda", dtype=torch.bfloat16)
+    a.q_rstd, a.q_rstd_stride_b, a.q_rstd_stride_l = rstd.data_ptr(), N, 1
+    a.q_norm_weight, a.q_norm_eps = wq.data_ptr(), 1e-6
 stream = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     assert lib.ltxmi_attention_fwd_bf16(ctypes.byref(a), stream) == 0
