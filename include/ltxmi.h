@@ -20,7 +20,7 @@
  *   - argument structs (ltxmi_*_args) MUST be zero-initialised before the fields in use are
  *     set (`ltxmi_gemm_args a = {0};` / memset): versions append optional fields at the tail
  *     (0.2: rowsumsq*, a_kblock* of ltxmi_gemm_args; q_rowsumsq*, q_norm*, rope_*, o_segment*
- *     of ltxmi_attn_args; 0.3: q_rstd*), and a zero there means "off".  A caller must be
+ *     of ltxmi_attn_args; 0.3: q_rstd*; 0.4: conv3d post_*), and a zero there means "off".  A caller must be
  *     rebuilt against the header of the library it loads.  An optional pointer that is NULL
  *     switches its companion size / stride fields off whatever they hold.
  */
@@ -261,6 +261,16 @@ typedef struct ltxmi_conv3d_args {
                                   four-wave (two workgroups per CU, Cout % 128 == 0) / eight-wave form whatever the
                                   grid (LTXMI_ERR_UNSUPPORTED if the direct convolution does not take the shape).
                                   Used by the parity tests to check the implementations against each other. */
+    /* 0.4 (optional, zeros = off): the norm2 -> SiLU that follows conv1 inside a ResnetBlock3D
+     * (causal_video_autoencoder.py:1226-1243) applied in the convolution's epilogue, from the fp32 accumulators:
+     * y = silu(pixelnorm(conv + bias) * (1 + post_scale[b]) + post_shift[b]), the arithmetic of
+     * ltxmi_pixelnorm_ada_silu_bf16 without the bf16 rounding in between.  Only where one wave holds all channels of a
+     * position: ltxmi_conv3d_fuses_post_norm() says whether a call would; post_norm = 1 on any other call is
+     * LTXMI_ERR_UNSUPPORTED (the caller then runs the PixelNorm launch itself). */
+    int32_t post_norm;         /* 0 off, 1 PixelNorm -> AdaLN -> SiLU                       */
+    const float* post_scale;   /* fp32 [B, Cout], or NULL together with post_shift          */
+    const float* post_shift;
+    float post_eps;            /* PixelNorm eps (pixel_norm.py: 1e-8)                       */
 } ltxmi_conv3d_args;
 
 /* Two implementations behind this entry, chosen by shape: a direct convolution with the input halo
@@ -268,6 +278,10 @@ typedef struct ltxmi_conv3d_args {
  * Cout is a multiple of 128, eight waves per workgroup otherwise) and an implicit GEMM (everything else).
  * Requirements for both: Cin % 64 == 0, Cout % 8 == 0, 16-byte aligned x / w. */
 int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* args, void* stream);
+/* 1 if ltxmi_conv3d_ndhwc_bf16(args) with post_norm = 1 would apply it in its epilogue (the four-wave direct convolution
+ * with Cout == 128, plain store, no `add`), 0 otherwise.  Reads the fields that choose the implementation (shape, flags, algo,
+ * bias != NULL); no launch. */
+int ltxmi_conv3d_fuses_post_norm(const ltxmi_conv3d_args* args);
 
 /* PixelNorm (pixel_norm.py:5-12, eps 1e-8) -> optional (1+scale)*x+shift per (batch, channel)
  * (ResnetBlock3D AdaLN, causal_video_autoencoder.py:1206-1243, Decoder tail :771-795)

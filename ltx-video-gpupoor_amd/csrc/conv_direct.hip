@@ -25,6 +25,7 @@ struct ConvDirectP {
     int B, T, H, W, Cin, Cout;
     int tpad, pad_replicate, tzero;
     int tiles_t, tiles_y, tiles_x, tiles_n;
+    const float* post_scale; const float* post_shift; float post_eps;      // EPI 3 only
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page_cd[16];
@@ -501,7 +502,7 @@ __device__ __forceinline__ int swz(int c, int r) { return c ^ (((r >> 2) & 1) <<
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p) {
-    constexpr bool ADD = (EPI == 1), D2S = (EPI == 2);
+    constexpr bool ADD = (EPI == 1), D2S = (EPI == 2), PNORM = (EPI == 3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* wst = smem + HALO_BYTES;
@@ -704,11 +705,44 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
     // ---- epilogue: 32 positions x 64 channels at a time through the wave's 4-KB LDS scratch (the halo is free)
     char* scr = smem + wave * 4096;
     const int ecol = (lane >> 4) * 4;
+    // EPI 3 (Cout == 128, so n0 == 0): PixelNorm over the 128 channels of a position -> (1 + scale) x + shift -> SiLU, from the
+    // fp32 accumulators.  A position's channels all live in this wave: 8 column blocks x 4 registers in each of the four lanes
+    // frow, frow + 16, + 32, + 48 -- the statistic is a lane-local sum and two cross-lane adds, no LDS exchange
+    float rstd_i[4];
+    if (PNORM) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32x2 bv = *(const u32x2*)(p.bias + j * 16 + ecol);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][j][0] += bf_lo(bv[0]); acc[i][j][1] += bf_hi(bv[0]);
+                acc[i][j][2] += bf_lo(bv[1]); acc[i][j][3] += bf_hi(bv[1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s2 += acc[i][j][e] * acc[i][j][e];
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            rstd_i[i] = rsqrtf(s2 * (1.0f / 128.0f) + p.post_eps);
+        }
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         u32x2 bias_v[4];
+        f32x4 sc_v[4], sh_v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bias_v[j] = *(const u32x2*)(p.bias + min(n0 + h * 64 + j * 16 + ecol, p.Cout - 4));
+        for (int j = 0; j < 4; ++j) {
+            if (!PNORM) bias_v[j] = *(const u32x2*)(p.bias + min(n0 + h * 64 + j * 16 + ecol, p.Cout - 4));
+            if (PNORM && p.post_scale) {
+                sc_v[j] = *(const f32x4*)(p.post_scale + (int64_t)b * 128 + h * 64 + j * 16 + ecol);
+                sh_v[j] = *(const f32x4*)(p.post_shift + (int64_t)b * 128 + h * 64 + j * 16 + ecol);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             u32x4 add_v[4];
@@ -729,8 +763,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 a4 = acc[i][h * 4 + j];
                     float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-                    v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
-                    v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
+                    if (PNORM) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float u = v[e] * rstd_i[i];
+                            if (p.post_scale) u = u * (1.0f + sc_v[j][e]) + sh_v[j][e];
+                            v[e] = silu_f(u);
+                        }
+                    } else {
+                        v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
+                        v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
+                    }
                     if (D2S && p.res) {
                         const int pos = wave * 64 + i * 16 + frow;
                         const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1);
@@ -786,14 +829,36 @@ extern "C" int ltxmi_debug_set_conv_stamps(void* buf) {
 #endif
 namespace ltxmi {
 
-// Returns -1 when the shape is not one this kernel takes (the caller then uses the implicit GEMM).
-int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
+#ifndef LTXMI_CD_V3
+#define LTXMI_CD_V3 1
+#endif
+// the shapes the direct convolution takes at all (either form)
+static bool conv3d_direct_takes(const ltxmi_conv3d_args* a) {
     const int st = a->stride_t > 0 ? a->stride_t : 1, sh = a->stride_hw > 0 ? a->stride_hw : 1;
     const int kt = a->kernel_t > 0 ? a->kernel_t : 3;
-    if (st != 1 || sh != 1 || kt != 3 || a->out_T > 0 || a->tpad > 0) return -1;
-    if (a->Cin % 64 != 0 || a->Cout % 8 != 0 || !a->bias) return -1;
-    if ((int64_t)a->B * a->T * a->H * a->W * a->Cin * 2 >= 0x7ffffff0ll) return -1;   // halo rows are addressed with 32-bit byte offsets
-    if (a->d2s && (a->Cout % 1024 != 0 || a->add)) return -1;          // a 128-column block must be one (p1 p2 p3)
+    if (st != 1 || sh != 1 || kt != 3 || a->out_T > 0 || a->tpad > 0) return false;
+    if (a->Cin % 64 != 0 || a->Cout % 8 != 0 || !a->bias) return false;
+    if ((int64_t)a->B * a->T * a->H * a->W * a->Cin * 2 >= 0x7ffffff0ll) return false;   // halo rows are addressed with 32-bit byte offsets
+    if (a->d2s && (a->Cout % 1024 != 0 || a->add)) return false;       // a 128-column block must be one (p1 p2 p3)
+    return true;
+}
+static int64_t conv3d_direct_grid(const ltxmi_conv3d_args* a) {
+    return (int64_t)a->B * ((a->T + CD_TT - 1) / CD_TT) * ((a->H + CD_TY - 1) / CD_TY) * ((a->W + CD_TX - 1) / CD_TX) * ((a->Cout + 127) / 128);
+}
+// whole 128-channel blocks: the four-wave form, two workgroups per CU (algo 3 asks for it, algo 4 for the eight-wave form)
+// (from 768 workgroups = 1.5 rounds of the chip's 512 slots; measured: 896 workgroups +5.8 %, 600 -0.6 %, 224 -21 %)
+static bool conv3d_direct_four_wave_form(const ltxmi_conv3d_args* a, int64_t grid) {
+    return a->Cout % 128 == 0 && grid < (1ll << 31) && ((LTXMI_CD_V3 && a->algo != 4 && grid >= 768) || a->algo == 3);
+}
+// ltxmi_conv3d_fuses_post_norm: the four-wave form with ONE 128-channel block (a wave then holds every channel of its positions)
+bool conv3d_direct_fuses_post_norm(const ltxmi_conv3d_args* a) {
+    return a->algo != 1 && conv3d_direct_takes(a) && a->Cout == 128 && !a->d2s && !a->add &&
+           conv3d_direct_four_wave_form(a, conv3d_direct_grid(a));
+}
+
+// Returns -1 when the shape is not one this kernel takes (the caller then uses the implicit GEMM).
+int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
+    if (!conv3d_direct_takes(a)) return -1;
     ConvDirectP p;
     p.x = (const uint16_t*)a->x; p.w = (const uint16_t*)a->w; p.bias = (const uint16_t*)a->bias;
     p.y = (uint16_t*)a->y; p.add = (const uint16_t*)a->add;
@@ -803,12 +868,9 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     p.tiles_t = (a->T + CD_TT - 1) / CD_TT; p.tiles_y = (a->H + CD_TY - 1) / CD_TY;
     p.tiles_x = (a->W + CD_TX - 1) / CD_TX; p.tiles_n = (a->Cout + 127) / 128;
     const int64_t grid = (int64_t)a->B * p.tiles_t * p.tiles_y * p.tiles_x * p.tiles_n;
-    // whole 128-channel blocks: the four-wave form, two workgroups per CU (algo 3 asks for it, algo 4 for the eight-wave form)
-#ifndef LTXMI_CD_V3
-#define LTXMI_CD_V3 1
-#endif
-    // (from 768 workgroups = 1.5 rounds of the chip's 512 slots; measured: 896 workgroups +5.8 %, 600 -0.6 %, 224 -21 %)
-    if (a->Cout % 128 == 0 && grid < (1ll << 31) && ((LTXMI_CD_V3 && a->algo != 4 && grid >= 768) || a->algo == 3)) {
+    p.post_scale = a->post_scale; p.post_shift = a->post_shift; p.post_eps = a->post_eps;
+    if (a->post_norm && !conv3d_direct_fuses_post_norm(a)) return -1;
+    if (conv3d_direct_four_wave_form(a, grid)) {
 #define LTXMI_CDV3_LAUNCH(E)                                                                                   \
         {                                                                                                      \
             static unsigned long long lds_done = 0;                                                            \
@@ -820,6 +882,7 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
         }
         if (a->d2s) LTXMI_CDV3_LAUNCH(2)
         else if (a->add) LTXMI_CDV3_LAUNCH(1)
+        else if (a->post_norm) LTXMI_CDV3_LAUNCH(3)
         else LTXMI_CDV3_LAUNCH(0)
 #undef LTXMI_CDV3_LAUNCH
         return check_launch("ltxmi_conv3d_ndhwc_bf16");

@@ -49,7 +49,8 @@ class Conv3dArgs(ctypes.Structure):
                 ("causal", c_int), ("pad_replicate", c_int), ("d2s", c_int), ("residual", c_void_p),
                 ("res_channels", c_int), ("add", c_void_p),
                 ("stride_t", c_int), ("stride_hw", c_int), ("tpad", c_int), ("out_T", c_int),
-                ("kernel_t", c_int), ("time_pad_zeros", c_int), ("algo", c_int)]
+                ("kernel_t", c_int), ("time_pad_zeros", c_int), ("algo", c_int),
+                ("post_norm", c_int), ("post_scale", c_void_p), ("post_shift", c_void_p), ("post_eps", c_float)]
 
 
 # name -> (restype, argtypes); mirrors include/ltxmi.h one to one
@@ -76,6 +77,7 @@ SIGNATURES = {
     "ltxmi_stg_blend_grouped_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int,
                                              c_void_p]),
     "ltxmi_conv3d_ndhwc_bf16": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
+    "ltxmi_conv3d_fuses_post_norm": (c_int, [ctypes.POINTER(Conv3dArgs)]),
     "ltxmi_pixelnorm_ada_silu_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                               c_int, c_float, c_void_p]),
     "ltxmi_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -148,11 +148,14 @@ class CausalConv3d(nn.Module):
         self._packed = None
         return super()._load_from_state_dict(*a, **k)
 
-    def forward(self, x, causal: bool = True, d2s=False, residual=None, add=None, tpad=0, out_T=0):
-        """x: NDHWC bf16."""
+    def forward(self, x, causal: bool = True, d2s=False, residual=None, add=None, tpad=0, out_T=0, post_norm=None):
+        """x: NDHWC bf16.  post_norm = (scale, shift, eps): the PixelNorm -> AdaLN -> SiLU that follows this convolution
+        (ops.conv3d: in its epilogue where the kernel holds all channels of a position, a second launch otherwise)."""
         w, b = self.packed(d2s)
+        if post_norm is not None and self.cout_padded != self.out_channels:
+            raise ValueError("ltxmi.CausalConv3d: post_norm on a convolution with padded output channels")
         return ops.conv3d(x, w, b, causal, self.pad_replicate, d2s=d2s, residual=residual, add=add,
-                          stride=self.stride, tpad=tpad, out_T=out_T)
+                          stride=self.stride, tpad=tpad, out_T=out_T, post_norm=post_norm)
 
 
 def make_conv_nd(dims, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
@@ -214,10 +217,14 @@ class ResnetBlock3D(nn.Module):
             ada = (self.scale_shift_table.float()[None] + timestep.float().reshape(B, 4, -1))
             sh1, sc1, sh2, sc2 = [t.contiguous() for t in ada.unbind(dim=1)]
         h = ops.pixelnorm_ada_silu(x, sc1, sh1, apply_silu=True)
-        h = self.conv1(h, causal=causal)
         if self.inject_noise:
+            h = self.conv1(h, causal=causal)
             h = h + self._spatial_noise(h, self.per_channel_scale1)
-        h = ops.pixelnorm_ada_silu(h, sc2, sh2, apply_silu=True, out=h)
+            h = ops.pixelnorm_ada_silu(h, sc2, sh2, apply_silu=True, out=h)
+        else:
+            # norm2 -> AdaLN -> SiLU (:1226-1243) rides on conv1: in its epilogue at the 128-channel stage (one wave holds all
+            # channels of a position there), as a launch on conv1's result elsewhere
+            h = self.conv1(h, causal=causal, post_norm=(sc2, sh2, 1e-8))
         if self.conv_shortcut is not None:
             s = self.norm3(x)
             Bx, T, H, W, C = s.shape

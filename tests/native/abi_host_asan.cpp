@@ -178,6 +178,24 @@ int main() {
     c.kernel_t = 0; c.time_pad_zeros = 1;
     expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(zero-padded time, no device)");
 
+    // post_norm (0.4): fused only by the four-wave direct convolution with Cout == 128; refused elsewhere, never launched blind
+    memset(&c, 0, sizeof c);
+    c.x = p; c.w = p; c.bias = p; c.y = p;
+    c.B = 1; c.T = 97; c.H = 128; c.W = 192; c.Cin = 128; c.Cout = 128; c.pad_replicate = 1;
+    if (ltxmi_conv3d_fuses_post_norm(&c) != 1) { fprintf(stderr, "FAIL fuses_post_norm(128 -> 128 at the decoder's last stage)\n"); ++g_bad; }
+    if (ltxmi_conv3d_fuses_post_norm(nullptr) != 0) { fprintf(stderr, "FAIL fuses_post_norm(NULL)\n"); ++g_bad; }
+    c.post_norm = 1; c.post_scale = pf; c.post_shift = pf; c.post_eps = 1e-8f;
+    expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(post_norm, no device)");
+    c.post_shift = nullptr;
+    expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(post_norm, scale without shift)", LTXMI_ERR_INVALID_ARG);
+    c.post_shift = pf; c.Cout = 256;
+    if (ltxmi_conv3d_fuses_post_norm(&c) != 0) { fprintf(stderr, "FAIL fuses_post_norm(Cout 256)\n"); ++g_bad; }
+    expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(post_norm at Cout 256)", LTXMI_ERR_UNSUPPORTED);
+    c.Cout = 128; c.algo = 1;
+    expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(post_norm on the implicit GEMM)", LTXMI_ERR_UNSUPPORTED);
+    c.algo = 0; c.add = p;
+    expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(post_norm with add)", LTXMI_ERR_UNSUPPORTED);
+
     // ---- VAE pointwise / layout kernels, guidance, conditioning, upsampler
     expect_fail(ltxmi_pixelnorm_ada_silu_bf16(nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0.f, nullptr), "pixelnorm(NULL)");
     expect_fail(ltxmi_pixelnorm_ada_silu_bf16(p, p, 13 * 32 * 48, 512, 13 * 32 * 48, pf, pf, 1, 1e-6f, nullptr), "pixelnorm(no device)");

@@ -777,6 +777,49 @@ def test_conv3d_direct_path(causal, mode, tzero, cin, cout, with_add, algo):
     check(ncdhw(out.cpu()), truth + (add.float() if with_add else 0), what=f"direct conv {cin}->{cout} algo {algo}")
 
 
+@pytest.mark.parametrize("cin,ada,causal", [(128, True, False), (64, False, True), (192, True, True)])
+def test_conv3d_post_norm_epilogue(cin, ada, causal):
+    """ltxmi_conv3d_args.post_norm: PixelNorm -> (1 + scale) x + shift -> SiLU of the result in the epilogue of the four-wave
+    direct convolution (Cout 128: one wave holds all channels of a position), from the fp32 accumulators -- against the oracle's
+    fp32 convolution followed by the same arithmetic in fp32, and against the two-launch form; partial tiles on every axis;
+    where the kernel cannot fuse (other forms / widths) the entry refuses and ops.conv3d runs the second launch."""
+    import ctypes
+    from ltxmi import ops, _lib
+    from oracle import vae as ov
+    B, T, H, W, cout = 2, 5, 36, 100, 128
+    x = rnd(B, cin, T, H, W, seed=114)
+    w = rnd(cout, cin, 3, 3, 3, seed=115, scale=(27 * cin) ** -0.5)
+    b = rnd(cout, seed=116)
+    scale, shift = (rnd(B, cout, seed=117, scale=0.3).float(), rnd(B, cout, seed=118, scale=0.3).float()) if ada else (None, None)
+    y = ov.causal_conv3d(x.float(), {"conv.weight": w.float(), "conv.bias": b.float()}, "", causal, "replicate")
+    n = y * torch.rsqrt(y.pow(2).mean(dim=1, keepdim=True) + 1e-8)
+    if ada:
+        n = n * (1 + scale[:, :, None, None, None]) + shift[:, :, None, None, None]
+    truth = torch.nn.functional.silu(n)
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous().to(DEV)
+    xd, bd = ndhwc(x).to(DEV), b.to(DEV)
+    pn = (scale.to(DEV) if ada else None, shift.to(DEV) if ada else None, 1e-8)
+    a = _lib.Conv3dArgs()
+    a.bias, a.B, a.T, a.H, a.W, a.Cin, a.Cout, a.causal, a.pad_replicate, a.algo = bd.data_ptr(), B, T, H, W, cin, cout, int(causal), 1, 3
+    assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 1
+    fused = ops.conv3d(xd, wp, bd, causal, True, algo=3, post_norm=pn)
+    check(ncdhw(fused.cpu()), truth, what=f"conv {cin}->128 + post_norm (fused epilogue)")
+    two = ops.conv3d(xd, wp, bd, causal, True, algo=3)
+    two = ops.pixelnorm_ada_silu(two, pn[0], pn[1], True, 1e-8)
+    check(fused, two.float(), rel_l2=4e-3, what="post_norm fused vs two launches")
+    # the forms that cannot: the eight-wave form / the implicit GEMM (ops.conv3d then launches the norm itself) ...
+    for algo in (4, 1):
+        a.algo = algo
+        assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 0
+        other = ops.conv3d(xd, wp, bd, causal, True, algo=algo, post_norm=pn)
+        check(other, two.float(), rel_l2=4e-3, what=f"post_norm as a second launch (algo {algo})")
+    # ... and the entry itself refuses post_norm = 1 there
+    a.algo, a.x, a.w, a.y = 4, xd.data_ptr(), wp.data_ptr(), two.data_ptr()
+    a.post_norm, a.post_eps = 1, 1e-8
+    assert _lib.lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), None) == -2        # LTXMI_ERR_UNSUPPORTED, nothing launched
+    assert b"post_norm" in _lib.lib.ltxmi_last_error()
+
+
 @pytest.mark.parametrize("cin,residual,red", [(256, True, 2), (128, False, 1)])
 @pytest.mark.parametrize("algo", [4, 3])
 def test_conv3d_direct_path_depth_to_space(cin, residual, red, algo, monkeypatch):

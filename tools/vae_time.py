@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""VAE decode timing only (bench.py's time_vae), for A/B runs with LTXMI_LIB."""
+"""VAE decode timing only (bench.py's time_vae), for A/B runs with LTXMI_LIB.
+    python tools/vae_time.py [iters]
+    python tools/vae_time.py --ab-post-norm [rounds]    in-process A/B: conv1's norm2 -> SiLU in the convolution's epilogue
+                                                        (ops.CONV_POST_NORM_FUSE) against the second launch, alternating decodes"""
 import os
 import sys
 
@@ -8,4 +11,27 @@ for p in (ROOT, os.path.join(ROOT, "ltx-video-gpupoor_amd")):
     sys.path.insert(0, p)
 import bench  # noqa: E402
 
-print(bench.time_vae("cuda", int(sys.argv[1]) if len(sys.argv) > 1 else 5), flush=True)
+if len(sys.argv) > 1 and sys.argv[1] == "--ab-post-norm":
+    import torch
+    import ltxmi
+    from ltxmi import ops
+    vae, z, ts = bench.make_vae("cuda")
+    outs, times = {}, {True: [], False: []}
+    with torch.no_grad():
+        for rnd_ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
+            for fuse in (True, False):
+                ops.CONV_POST_NORM_FUSE = fuse
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = ltxmi.vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd_ > 0:
+                    times[fuse].append(e0.elapsed_time(e1))
+                outs[fuse] = out
+    med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
+    d = float((outs[True].float() - outs[False].float()).norm() / outs[False].float().norm())
+    print(f"decode 768x512x97: post_norm in conv1's epilogue {med[True]:.3f} ms | as a second launch {med[False]:.3f} ms "
+          f"(x{med[False] / med[True]:.4f}); the two renderings differ by {d:.2e} relative L2", flush=True)
+else:
+    print(bench.time_vae("cuda", int(sys.argv[1]) if len(sys.argv) > 1 else 5), flush=True)
