@@ -534,6 +534,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     // through LDS every store instruction writes 8 whole 128-byte lines, 16 bytes per lane, and the
     // instruction count halves (the store tail is issue-bound: cdna guide T21).
     char* scr = smem + 2 * STAGE_BYTES + wave * 4096;
+    // The residual comes in ROW-MAJOR, 16 bytes per lane through a buffer descriptor (8 whole 128-byte lines per instruction,
+    // 32-bit offsets), one 32 x 64 chunk ahead of its use, and is turned into the accumulator layout through the wave's LDS
+    // scratch -- the store path backwards.  (Requested per 16-row block in the accumulator layout -- 8-byte pieces, every line
+    // touched by four instructions, 64-bit address arithmetic per piece -- it was 2 % slower on the K = 2048 launches.  The
+    // loads stay the expensive part of this epilogue: stamps, 20.8 k cycles per tile against 7.2 k without them; hoisting all
+    // of them, a second chunk in flight, issuing them ahead of the next tile's LDS-DMA pieces: measured, none helped --
+    // profiles/r03_gemm_residual_rowmajor.log.)
+    static_assert(!RESID || NH == 1, "the residual prefetch numbers its chunks within one 64-column half");
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.R, 0, RESID ? (uint32_t)(((int64_t)(p.M - 1) * p.ldr + p.N) * 2) : 0u, 0x00020000);
+    u32x4 rres[4];
+    auto load_res = [&](int m0, int n0, int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // (rows >= M / columns >= N: outside the descriptor, read as zeros; their results are never stored)
+            const int m = m0 + wm * WM + c * 32 + t * 8 + (lane >> 3);
+            const int n = n0 + wn * WN + (lane & 7) * 8;
+            const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((int64_t)m * p.ldr + n) * 2) : 0xfffffff0u;
+            rres[t] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);
+        }
+    };
     auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
 #pragma unroll
       for (int jh = 0; jh < NH; ++jh) {                                   // one 64-column half of the sub-tile at a time
@@ -547,8 +568,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
             bias_v[j] = *(const u32x2*)(p.bias + ncl[j] * p.bias_stride);
             if (GATED) gt_v[j] = *(const u32x2*)(p.gate_table + ncl[j]);
         }
+        if (RESID) load_res(m0, n0, 0);
 #pragma unroll
         for (int c = 0; c < MI / 2; ++c) {
+            u32x2 rr_c[2][NE];
+            if (RESID) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row_l = t * 8 + (lane >> 3), chunk = lane & 7;
+                    *(u32x4*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4)) = rres[t];
+                }
+                if (c + 1 < MI / 2) load_res(m0, n0, c + 1);
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        const int row_l = ii * 16 + erow, chunk = j * 2 + (lane >> 5);
+                        rr_c[ii][j] = *(const u32x2*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4) + ((lane >> 4) & 1) * 8);
+                    }
+            }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 const int i = 2 * c + ii;
@@ -559,7 +597,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     if (GATED) ge_v[j] = *(const u32x2*)(gate_row + ncl[j]);
-                    if (RESID) rr_v[j] = *(const u32x2*)(p.R + (int64_t)mc * p.ldr + ncl[j]);
+                    if (RESID) rr_v[j] = rr_c[ii][j];
                 }
                 const int row_l = ii * 16 + erow;
                 float ss = 0.f;
@@ -993,7 +1031,10 @@ extern "C" int ltxmi_gemm_bf16(const ltxmi_gemm_args* a, void* stream) {
     if (a->M >= 768 && a->N >= 256 && t256 >= persist_min) {
         const bool fits32 = ((int64_t)a->M * a->ldc * 2 < (1ll << 32)) && ((int64_t)256 * a->lda * 2 < (1ll << 31)) &&
                             ((int64_t)256 * a->ldw * 2 < (1ll << 31));
-        if (a->K >= 128 && fits32 && force_tile != 256)
+        // (the persistent kernel reads the residual through a buffer descriptor, in 16-byte pieces)
+        const bool res16 = !a->residual || (a->ldr % 8 == 0 && (((uintptr_t)a->residual) & 15) == 0 &&
+                                            (int64_t)a->M * a->ldr * 2 < (1ll << 32));
+        if (a->K >= 128 && fits32 && res16 && force_tile != 256)
             return launch_persistent<256, 256, 2, 4>(p, epi, s, "ltxmi_gemm_bf16");
         return launch_tile<256, 256, 2, 4, 0>(p, epi, s, "ltxmi_gemm_bf16");
     }

@@ -25,7 +25,8 @@ def main():
     names = [os.path.basename(p) for p in sys.argv[1:]]
     shapes = [(14976, 8192, 2048, 1, "ff1"), (14976, 2048, 8192, 3, "ff2"), (14976, 6144, 2048, 0, "qkv"),
               (14976, 6144, 2048, 6, "qkv+ss"), (14976, 2048, 2048, 6, "q2+ss"),
-              (14976, 2048, 2048, 3, "to_out"), (4992, 8192, 2048, 1, "ff1 B1"), (8192, 8192, 8192, 0, "8k^3")]
+              (14976, 2048, 2048, 3, "to_out"), (14976, 2048, 2048, 7, "to_out gated"), (14976, 2048, 8192, 7, "ff2 gated"),
+              (4992, 8192, 2048, 1, "ff1 B1"), (8192, 8192, 8192, 0, "8k^3")]
     stream = torch.cuda.current_stream().cuda_stream
     for (M, N, K, epi, name) in shapes:
         a = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
@@ -35,12 +36,17 @@ def main():
         res = torch.randn(M, N, device="cuda").to(torch.bfloat16)
         g = _lib.GemmArgs()
         g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc = a.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), out.data_ptr(), N
-        g.M, g.N, g.K, g.epilogue = M, N, K, (0 if epi == 6 else epi)
+        g.M, g.N, g.K, g.epilogue = M, N, K, (0 if epi == 6 else 3 if epi == 7 else epi)
         if epi == 6:                                 # plain epilogue + row sums of squares over the first 2048 columns
             ss = torch.empty(M, 32, device="cuda", dtype=torch.float32)
             g.rowsumsq, g.rowsumsq_cols, g.rowsumsq_ld = ss.data_ptr(), 2048, 32
-        if epi == 3:
+        if epi in (3, 7):
             g.residual, g.ldr = res.data_ptr(), N
+        if epi == 7:                                 # x + (table + temb[batch element]) * (A W^T + b): attn1.to_out / ff.net.2 of a block
+            g.epilogue = 3
+            gtab = torch.randn(N, device="cuda").to(torch.bfloat16)
+            gemb = torch.randn(3, 6 * N, device="cuda").to(torch.bfloat16)
+            g.gate_table, g.gate_temb, g.gate_ld, g.rows_per_group = gtab.data_ptr(), gemb.data_ptr() + 2 * 2 * N, 6 * N, M // 3
         times = [[] for _ in libs]
         ref = None
         for rep in range(7):

@@ -20,7 +20,7 @@ _lib.lib.ltxmi_debug_set_gemm_stamps.argtypes = [ctypes.c_void_p]
 assert _lib.lib.ltxmi_debug_set_gemm_stamps(buf.data_ptr()) == 0
 algos = [int(a) for a in sys.argv[1:]] or [0]
 for (M, N, K, epi, name) in [(14976, 8192, 2048, ops.EPI_GELU_TANH, "ff1"), (14976, 2048, 8192, ops.EPI_GATE_RESIDUAL, "ff2"),
-                             (8192, 8192, 8192, ops.EPI_NONE, "8k^3")]:
+                             (14976, 2048, 2048, ops.EPI_GATE_RESIDUAL, "to_out"), (8192, 8192, 8192, ops.EPI_NONE, "8k^3")]:
     a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
     b = torch.randn(N, device=dev).to(torch.bfloat16)
