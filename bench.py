@@ -170,6 +170,86 @@ class StepRunner:
         self.ops.guidance_step_(noise_pred, self.latents, self.dt, 3.0, 1.0, 0.7, True, True, True, self.ws)
 
 
+def time_config3_step(runner, ops, steps):
+    """BASELINE config 3 on ONE GPU (the N = 1 anchor of its 1 -> 8 curve): 2B i2v 1216x704x121 = 16 x 22 x 38 = 13 376 tokens,
+    first latent frame conditioned (per-token timesteps, pipeline_ltx_video.py:1123-1166), B_eff 3, 28 layers + guidance /
+    Euler.  Parity at this size: tests/test_gpu_model.py::test_transformer_config3_*."""
+    n3 = GRID_CONFIG3[0] * GRID_CONFIG3[1] * GRID_CONFIG3[2]
+    steps = max(3, min(steps, 10))
+    runner.set_grid(GRID_CONFIG3, image_conditioned=True)
+    try:
+        for _ in range(2):
+            runner.step()
+        key = ("attention", NUM_CONDS, H, n3, n3, DH)
+        ops.watch_launches([key])
+        e, per = timed_steps(runner.step, steps, None)
+        at = ops.launch_times_ms().get(key, [])
+        ops.watch_launches(None)
+        assert torch.isfinite(runner.latents).all(), "config 3: non-finite latents"
+    finally:
+        runner.set_grid(GRID)
+    # per cond: GEMM 28 D^2 N L (+ text K/V) = 44.0, attention 4 N^2 D L = 41.1 TFLOP
+    tflop = NUM_CONDS * (28.0 * D * D * n3 * L + 4.0 * D * D * T_TEXT * L + 4.0 * n3 * n3 * D * L) / 1e12
+    ms = e / steps * 1e3
+    at_ms = sum(at) / max(len(at), 1)
+    at_tf = 4.0 * NUM_CONDS * n3 * n3 * D / (at_ms * 1e-3) / 1e12 if at_ms > 0 else 0.0
+    return {"workload": "LTX-Video 2B i2v 1216x704x121 (13376 tokens, first latent frame conditioned: per-token timesteps), "
+                        "B_eff 3, 28 layers + guidance/Euler, ONE GPU", "tokens": n3, "steps": steps,
+            "denoise_steps_per_s": round(steps / e, 4), "ms_per_step": round(ms, 2),
+            "step_ms": {"median": round(pct(per, 0.5), 3), "p10": round(pct(per, 0.1), 3), "p90": round(pct(per, 0.9), 3)},
+            "algorithmic_tflop_per_step": round(tflop, 1), "step_tflops": round(tflop / (ms * 1e-3), 1),
+            "attention_launch_ms": round(at_ms, 4), "attention_tflops": round(at_tf, 1),
+            "attention_frac_of_mfma_peak": round(at_tf / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+
+def ulysses_projection(runner, ops, steps):
+    """NOT a measurement of sequence parallelism -- a compute-only projection from ONE GPU, for rounds without a
+    multi-GPU node: one rank's share of a P-rank Ulysses step (N/P local tokens through every token-local kernel, the
+    destination-major pack, attention of H/P heads over all N keys, the K-blocked to_out) timed here with both all-to-alls
+    replaced by the identity (UlyssesAttnProcessor(simulate_world=P)), plus an xGMI term from DESIGN section 6's bytes per
+    layer: each rank sends 3 B (N/P) (D/P) 2 bytes to every peer and gets B (N/P) (D/P) 2 back, every peer pair on a link
+    of its own at ~153 GB/s (MI355X_MICROARCH.md).  Latency, RCCL launch overhead and the overlap mode are not modelled."""
+    from ltxmi import distributed as sp
+    steps = max(3, min(steps, 10))
+    out = {"label": "compute-only projection from one GPU, NOT a measurement (exchanges replaced by the identity; xGMI "
+                    "term = bytes / 153 GB/s per link, no latency, no overlap)", "configs": {}}
+    for name, grid, cond in (("config2_4992", GRID, False), ("config3_13376", GRID_CONFIG3, True)):
+        runner.set_grid(grid, image_conditioned=cond)
+        full = (runner.latents, runner.freqs, runner.t_dev, runner.grid, runner.n_tok)
+        for _ in range(2):
+            runner.step()
+        e1, _ = timed_steps(runner.step, steps, None)
+        t1 = e1 / steps * 1e3
+        res = {"tokens": runner.n_tok, "t1_ms": round(t1, 2), "ranks": {}}
+        for P in (2, 4, 8):
+            nl = runner.n_tok // P
+            if runner.n_tok % P or H % P or (cond and nl % (grid[1] * grid[2])):
+                res["ranks"][str(P)] = {"skipped": "tokens / heads / whole frames not divisible"}
+                continue
+            for blk in runner.m.transformer_blocks:
+                blk.attn1.set_processor(sp.UlyssesAttnProcessor(simulate_world=P))
+            runner.latents = full[0][:, :nl].contiguous()
+            runner.freqs = tuple(t[:, :nl].contiguous() for t in full[1])
+            runner.t_dev = full[2][:, :nl].contiguous() if cond else full[2]
+            runner.grid = (grid[0] // P, grid[1], grid[2]) if cond else grid
+            try:
+                for _ in range(2):
+                    runner.step()
+                eP, _ = timed_steps(runner.step, steps, None)
+            finally:
+                runner.latents, runner.freqs, runner.t_dev, runner.grid, runner.n_tok = full
+                sp.disable_sequence_parallel(runner.m)
+            tP = eP / steps * 1e3
+            per_peer = (3 + 1) * NUM_CONDS * nl * (D // P) * 2                 # q,k,v out + o back, bytes to ONE peer per layer
+            xgmi_ms = L * per_peer / 153e9 * 1e3
+            res["ranks"][str(P)] = {"t_rank_ms": round(tP, 2), "compute_speedup": round(t1 / tP, 3),
+                                    "compute_efficiency": round(t1 / tP / P, 3), "xgmi_ms_per_step": round(xgmi_ms, 3),
+                                    "projected_speedup_with_exposed_exchange": round(t1 / (tP + xgmi_ms), 3)}
+        out["configs"][name] = res
+    runner.set_grid(GRID)
+    return out
+
+
 def pct(xs, q):
     xs = sorted(xs)
     return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
@@ -842,6 +922,8 @@ def main():
                                             "before its first skipped block + prompt K/V projected once per "
                                             "generation (both exact); not part of `value`"}
         ops.set_step_invariant_caching(False)
+        line["config3_step_1gpu"] = time_config3_step(runner, ops, args.steps)
+        line["ulysses_projection"] = ulysses_projection(runner, ops, args.steps)
         del runner
         torch.cuda.empty_cache()
         line["attention"] = {

@@ -213,7 +213,7 @@ class AttnProcessor2_0:
     epilogue that updates ``residual`` in place and returns it; without it the plain
     ``to_out[0]`` result is returned exactly like the reference."""
 
-    def __call__(self, attn: Attention, hidden_states_wrapper, freqs_cis=None, encoder_hidden_states=None,
+    def __call__(self, attn: Attention, hidden_states_wrapper, freqs_cis, encoder_hidden_states=None,
                  attention_mask=None, temb=None, skip_layer_mask=None, skip_layer_strategy=None,
                  fused_residual=None, *args, **kwargs):
         hidden_states = hidden_states_wrapper[0]
@@ -290,12 +290,18 @@ class AttnProcessor2_0:
             if hit is None:
                 # this forward's stacked projection (Transformer3DModel._stacked_text_kv): rows of the FULL batch's text states;
                 # a block run on the leading rows of the batch takes the leading rows
-                ready = attn.__dict__.pop("_text_kv_ready", None)
+                # or on a micro-batch of rows (sequence-parallel overlap mode) takes ITS rows: any whole-row offset into the
+                # full tensor is served; the entry lives until the end of the forward (Transformer3DModel.forward drops it)
+                ready = attn.__dict__.get("_text_kv_ready")
                 if ready is not None:
                     full, full_version, kv_full = ready
-                    if (ehs.data_ptr() == full.data_ptr() and ehs.shape[1:] == full.shape[1:] and Bk <= full.shape[0]
-                            and ehs.dtype == full.dtype and ehs.is_contiguous() and ops.tensor_version(full) == full_version):
-                        hit = (kv_full[:Bk * Lk],)
+                    row_bytes = full.stride(0) * full.element_size()
+                    off = ehs.data_ptr() - full.data_ptr()
+                    if (row_bytes > 0 and off >= 0 and off % row_bytes == 0 and ehs.shape[1:] == full.shape[1:]
+                            and off // row_bytes + Bk <= full.shape[0] and ehs.dtype == full.dtype and ehs.is_contiguous()
+                            and ops.tensor_version(full) == full_version):
+                        r0 = off // row_bytes
+                        hit = (kv_full[r0 * Lk:(r0 + Bk) * Lk],)
             if hit is None:
                 kv = ops.gemm(ehs.reshape(Bk * Lk, -1), wkv, bkv)                  # [B*Lk, 2D]
                 ops.rmsnorm_rope_(kv[:, :D], attn.k_norm.weight, attn.k_norm.eps)
@@ -387,6 +393,13 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn, final_dropout=final_dropout,
                               inner_dim=ff_inner_dim, bias=ff_bias)
         self.scale_shift_table = nn.Parameter(torch.randn(6, dim) / dim ** 0.5)
+
+    def prepare_shared_state(self):
+        """Build, on the CURRENT stream, what the processors create lazily and cache for every later caller (the packed
+        projection weights).  Called by the micro-batched block loop before its side streams fork."""
+        self.attn1.packed_qkv()
+        if self.attn2 is not None:
+            self.attn2.packed_kv()
 
     def forward(self, hidden_states, freqs_cis=None, attention_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, timestep=None, cross_attention_kwargs=None, class_labels=None,

@@ -29,14 +29,17 @@ def _key_bias_from_mask(attention_mask, B, Lk):
                 f"(mask dim {d} has size {m.shape[d]} with stride {m.stride(d)})")
     # every block of a forward passes the same mask: keep its fp32 form (one conversion kernel per
     # forward instead of one per layer); keyed on storage + version so an in-place edit invalidates it
+    # (a few entries: the micro-batches of the sequence-parallel overlap mode pass row slices of one mask in turn)
     key = (m.data_ptr(), tuple(m.shape), tuple(m.stride()), m.dtype, ops.tensor_version(m))
-    global _BIAS_CACHE
-    if _BIAS_CACHE is None or _BIAS_CACHE[0] != key:
-        _BIAS_CACHE = (key, m[:, 0, 0, :].to(torch.float32).contiguous(), m)     # m kept alive: no pointer reuse
-    return _BIAS_CACHE[1]
+    hit = _BIAS_CACHE.get(key)
+    if hit is None:
+        if len(_BIAS_CACHE) >= 4:
+            _BIAS_CACHE.clear()
+        hit = _BIAS_CACHE[key] = (m[:, 0, 0, :].to(torch.float32).contiguous(), m)     # m kept alive: no pointer reuse
+    return hit[0]
 
 
-_BIAS_CACHE = None
+_BIAS_CACHE = {}
 
 
 @torch.compiler.disable()
@@ -44,7 +47,13 @@ def pay_attention(qkv_list, dropout_p=0., softmax_scale=None, causal=False, wind
                   deterministic=False, version=None, force_attention=None, attention_mask=None,
                   cross_attn=False, q_lens=None, k_lens=None, q_norm=None, rope=None):
     """``q_norm`` / ``rope`` (extension, used by AttnProcessor2_0 only): q is the raw projection output and is
-    RMS-normalised (+ rotated) by the kernel while it loads it -- see ops.attention."""
+    RMS-normalised (+ rotated) by the kernel while it loads it -- see ops.attention.
+
+    ``softmax_scale``: HONOURED here.  The reference's eager branch drops it on the floor (``sdpa_wrapper`` calls
+    ``F.scaled_dot_product_attention`` without ``scale=``, wan/modules/attention.py:99-116, so that branch always uses
+    1/sqrt(head_dim)) while its flash / sage branches pass it on (:344-347, :394-399); every caller in the reference
+    leaves it ``None`` (= 1/sqrt(head_dim) in all branches), where the two readings coincide.  A caller that does pass a
+    scale gets what the argument says -- the behaviour of the reference's non-eager back-ends, not of its sdpa branch."""
     q, k, v = qkv_list
     qkv_list.clear()
     if (q_norm is not None or rope is not None) and (q_lens is not None or k_lens is not None):

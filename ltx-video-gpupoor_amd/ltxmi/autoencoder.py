@@ -802,6 +802,30 @@ class CausalVideoAutoencoder(nn.Module):
         return DecoderOutput(sample=decoded)
 
 
+def _scaling_factor(vae):
+    cfg = getattr(vae, "_config", None)
+    return float(cfg.get("scaling_factor", 1.0)) if cfg is not None else float(vae.config.scaling_factor)
+
+
+def normalize_latents(latents, vae, vae_per_channel_normalize: bool = False):
+    """vae_encode.py:228-236, for callers that hold latents outside the encode / decode calls (inside them the
+    statistics ride on the layout kernels)."""
+    if vae_per_channel_normalize:
+        mean = vae.mean_of_means.to(latents.dtype).to(latents.device).view(1, -1, 1, 1, 1)
+        std = vae.std_of_means.to(latents.dtype).to(latents.device).view(1, -1, 1, 1, 1)
+        return (latents - mean) / std
+    return latents * _scaling_factor(vae)
+
+
+def un_normalize_latents(latents, vae, vae_per_channel_normalize: bool = False):
+    """vae_encode.py:239-247."""
+    if vae_per_channel_normalize:
+        mean = vae.mean_of_means.to(latents.dtype).to(latents.device).view(1, -1, 1, 1, 1)
+        std = vae.std_of_means.to(latents.dtype).to(latents.device).view(1, -1, 1, 1, 1)
+        return latents * std + mean
+    return latents / _scaling_factor(vae)
+
+
 def vae_encode(media_items, vae: CausalVideoAutoencoder, split_size: int = 1, vae_per_channel_normalize=False,
                generator: Optional[torch.Generator] = None, sample_posterior: bool = True):
     """vae_encode.py:22-91: pixels [B,3,F,H,W] (or [B,3,H,W]) in [-1,1] -> normalised latents [B,C,f,h,w].

@@ -82,7 +82,9 @@ def head_to_seq_shard(o, group=None):
 def usp_attn_forward(qkv, softmax_scale, group=None, attn_fn: Optional[Callable] = None):
     """Ulysses self-attention on a packed, already normed/roped projection buffer (generic form, any attention
     function; the product path below is the zero-copy form of the same exchange).
-    qkv: [B, N/P, 3, H, dh] -> returns [B, N/P, H, dh]."""
+    qkv: [B, N/P, 3, H, dh] -> returns [B, N/P, H, dh].
+    Name from wan/distributed/xdit_context_parallel.py:149; the signature there (``self, x, seq_lens, grid_sizes, freqs,
+    dtype``) belongs to ``WanSelfAttention.forward`` and is not reproduced."""
     if attn_fn is None:
         from . import ops
         attn_fn = lambda q, k, v, scale: ops.attention(q, k, v, softmax_scale=scale)   # noqa: E731
@@ -113,10 +115,23 @@ class UlyssesAttnProcessor:
     collectives whatever its rows are; (2) an ``attention_mask`` for self-attention is not supported (the reference's
     LTX path never passes one, transformer3d.py:411-415 builds the mask for the text keys only)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, exchange_at_world_1=None, simulate_world=None):
+        """``simulate_world`` (bench.py's compute-only projection, never a product setting): run ONE rank's share of a
+        P-rank step on this GPU -- N/P local tokens, the pack kernel for P destinations, attention of H/P heads over all N
+        keys, the K-blocked to_out -- with both exchanges replaced by the identity (the buffers have the exchanged
+        buffers' shapes; their CONTENT is not what a real exchange would deliver, so only the time means anything).
+        ``exchange_at_world_1``: at world size 1 both all-to-alls are identities and are skipped (RCCL would copy the
+        buffers); True -- or LTXMI_SP_FORCE_EXCHANGE=1 in the environment -- issues them anyway, which puts
+        ``dist.all_to_all_single`` (RCCL on a GPU) on the real zero-copy send / receive buffers and the K-blocked
+        ``to_out`` operand on a one-GPU box (tests/test_gpu_model.py)."""
+        import os
         self.group = group
+        if exchange_at_world_1 is None:
+            exchange_at_world_1 = os.environ.get("LTXMI_SP_FORCE_EXCHANGE", "0") == "1"
+        self.exchange_at_world_1 = bool(exchange_at_world_1)
+        self.simulate_world = int(simulate_world) if simulate_world else None
 
-    def __call__(self, attn, hidden_states_wrapper, freqs_cis=None, encoder_hidden_states=None,
+    def __call__(self, attn, hidden_states_wrapper, freqs_cis, encoder_hidden_states=None,
                  attention_mask=None, temb=None, skip_layer_mask=None, skip_layer_strategy=None,
                  fused_residual=None, *args, **kwargs):
         from . import ops
@@ -126,7 +141,7 @@ class UlyssesAttnProcessor:
         assert encoder_hidden_states is None, "UlyssesAttnProcessor is for self-attention"
         if attention_mask is not None:
             raise NotImplementedError("UlyssesAttnProcessor: a self-attention mask is not on this path")
-        P = dist.get_world_size(self.group)
+        P = self.simulate_world or dist.get_world_size(self.group)
         B, Nl, _ = hidden_states.shape
         D, H = attn.inner_dim, attn.heads
         dh = D // H
@@ -140,7 +155,8 @@ class UlyssesAttnProcessor:
         assert attn.q_norm.eps == attn.k_norm.eps
         send = ops.qkv_norm_rope_pack(qkv, B, Nl, D, P, attn.q_norm.weight, attn.k_norm.weight, attn.q_norm.eps,
                                       cos2, sin2, cos2.shape[0])                            # [P, Nl, B, 3, Dp]
-        if P > 1:
+        exchange = (P > 1 or self.exchange_at_world_1) and not self.simulate_world
+        if exchange:
             recv = torch.empty_like(send)
             dist.all_to_all_single(recv, send, group=self.group)
         else:
@@ -149,7 +165,7 @@ class UlyssesAttnProcessor:
         q, k, v = (full[:, :, i].permute(1, 0, 2, 3) for i in range(3))                     # [B, N, Hl, dh] views
         osend = torch.empty((P, B, Nl, Hl, dh), dtype=qkv.dtype, device=qkv.device)
         ops.attention(q, k, v, out=osend[0], softmax_scale=attn.scale, out_segments=(Nl, B * Nl * Dp))
-        if P > 1:
+        if exchange:
             orecv = torch.empty_like(osend)
             dist.all_to_all_single(orecv, osend, group=self.group)                          # [P src][B*Nl][Dp]
         else:
@@ -165,7 +181,9 @@ class UlyssesAttnProcessor:
                 ops.stg_blend_grouped_(orecv.view(P, B, Nl, Dp), hidden_states, m_dev)
         w_o, b_o = attn.to_out[0].weight, attn.to_out[0].bias
         a_blk0 = orecv[0].view(B * Nl, Dp)
-        kb = dict(a_kblock=Dp, a_kblock_stride=B * Nl * Dp) if P > 1 else {}
+        # the K-blocked reading of the receive buffer ([P src][B Nl][Dp]); at P = 1 there is one block = the plain matrix,
+        # described as K-blocked only when the exchange is forced (so that code path runs on one GPU too)
+        kb = dict(a_kblock=Dp, a_kblock_stride=B * Nl * Dp) if (P > 1 or (exchange and Dp % 64 == 0)) else {}
         if fused_residual is not None:
             residual, gate_table, gate_temb, rpg = fused_residual
             ops.gemm(a_blk0, w_o, b_o, out=residual.reshape(B * Nl, -1),
@@ -175,8 +193,13 @@ class UlyssesAttnProcessor:
         return ops.gemm(a_blk0, w_o, b_o, **kb).view(B, Nl, -1)
 
 
-def enable_sequence_parallel(model, group=None, overlap=True):
+def enable_sequence_parallel(model, group=None, overlap=True, bind_forward=False, exchange_at_world_1=None):
     """Install the Ulysses processor on every block's self-attention.
+
+    ``bind_forward`` (the reference's pattern for its Wan model, ``wan/text2video.py``: ``model.forward =
+    types.MethodType(usp_dit_forward, model)``): rebind ``model.forward`` to ``usp_dit_forward`` so that an unchanged caller
+    -- ``LTXVideoPipeline.__call__`` -- runs sequence-parallel; every rank passes the full inputs and gets the full
+    output.  ``disable_sequence_parallel`` undoes both.
 
     ``overlap`` (default on; takes effect at world size > 1 with >= 2 batch rows): the block loop runs the batch as TWO
     micro-batches, each on a stream of its own (``Transformer3DModel.forward(_microbatches=...)``).  Inside a block
@@ -186,11 +209,45 @@ def enable_sequence_parallel(model, group=None, overlap=True):
     kernel, so the result is the same as without the split (tests: world size 2, torch.equal)."""
     for blk in model.transformer_blocks:
         assert isinstance(blk, BasicTransformerBlock)
-        blk.attn1.set_processor(UlyssesAttnProcessor(group))
+        blk.attn1.set_processor(UlyssesAttnProcessor(group, exchange_at_world_1))
     model._sp_group = group
     model._sp_overlap = bool(overlap)
     model._sp_interrupt = _InterruptAgreement()
+    model.__dict__.pop("forward", None)
+    if bind_forward:
+        import types
+
+        def forward(self, hidden_states, freqs_cis, **kw):
+            kw.setdefault("group", self._sp_group)
+            return_dict = kw.pop("return_dict", True)
+            out = usp_dit_forward(self, hidden_states, freqs_cis, _unbound=True, **kw)
+            if out[0] is None or not return_dict:
+                return out
+            from .transformer3d import Transformer3DModelOutput
+            return Transformer3DModelOutput(sample=out[0])
+
+        model.forward = types.MethodType(forward, model)
     return model
+
+
+def disable_sequence_parallel(model):
+    """Back to the default processor and the class's own ``forward``."""
+    from .attention import AttnProcessor2_0
+    for blk in model.transformer_blocks:
+        blk.attn1.set_processor(AttnProcessor2_0())
+    for k in ("forward", "_sp_group", "_sp_overlap", "_sp_interrupt"):
+        model.__dict__.pop(k, None)
+    return model
+
+
+def begin_generation(model):
+    """Call at the start of every generation (``LTXVideoPipeline.__call__`` does): drops an interrupt agreement that was
+    posted by the LAST forward of the previous generation and never consumed -- the reference resets ``_interrupt`` per
+    generation, and a stale agreed flag would make the new generation's first forward return ``[None]`` on every rank.
+    Must be called by every rank (it is local: no collective)."""
+    agree = model.__dict__.get("_sp_interrupt")
+    if agree is not None:
+        agree.reset()
 
 
 def microbatch_slices(B):
@@ -206,11 +263,25 @@ class _InterruptAgreement:
     host in the same forward would drain the launch queue once per denoise step (the host runs about a step ahead of the
     device); instead forward k posts its flag -- all-reduce, then an asynchronous copy into pinned host memory behind an
     event -- and forward k + 1 reads it: no host synchronisation on a step's critical path, every rank sees the same
-    value in the same forward, and a cancel takes effect one forward (one denoise step) after it was raised."""
+    value in the same forward, and a cancel takes effect one forward (one denoise step) after it was raised.
+
+    Contract for callers: leave the loop ONLY on the ``[None]`` a forward returns, never on the rank-local flag (a rank
+    that stopped issuing forwards by itself would leave the others in forward k + 1's collectives); and call
+    ``begin_generation(model)`` before the first forward of a generation, so that a flag posted by the previous
+    generation's last forward (never read: there was no forward k + 1) is not taken for a cancel of the new one."""
 
     def __init__(self):
         self.pending = None
         self.consts = {}
+
+    def reset(self):
+        """Drop a posted-but-unread flag (start of a new generation, ``begin_generation``).  The copy into the pinned
+        word is drained first, so a late write cannot land in the next generation's first read."""
+        if self.pending is not None:
+            _, ev = self.pending
+            if ev is not None:
+                ev.synchronize()
+        self.pending = None
 
     def poll_and_post(self, local_flag, device, group):
         agreed = False
@@ -243,10 +314,14 @@ class _InterruptAgreement:
 
 def usp_dit_forward(model, hidden_states, freqs_cis, encoder_hidden_states=None, timestep=None,
                     encoder_attention_mask=None, skip_layer_mask=None, skip_layer_strategy=None,
-                    latent_shape=None, group=None, **kw):
+                    latent_shape=None, group=None, _unbound=False, **kw):
     """Sequence-parallel ``Transformer3DModel.forward``: shard tokens (and the per-token inputs that
     follow them), run the model on the local shard, all-gather the output.  Every rank passes the
-    FULL inputs and receives the FULL output, so it is a drop-in for ``model(...)``."""
+    FULL inputs and receives the FULL output, so it is a drop-in for ``model(...)``.
+
+    The NAME is the reference's (wan/distributed/xdit_context_parallel.py:66), the signature is not: there it is a
+    replacement for ``WanModel.forward(self, x, t, context, seq_len, clip_fea=None, y=None)`` -- a model outside this
+    path -- and here it wraps ``Transformer3DModel.forward`` and so takes THAT method's arguments."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     N = hidden_states.shape[1]
     hs = shard_tokens(hidden_states, rank, world)
@@ -267,9 +342,14 @@ def usp_dit_forward(model, hidden_states, freqs_cis, encoder_hidden_states=None,
         kw["ltxv_model"] = _Frozen()
     if getattr(model, "_sp_overlap", False) and world > 1 and hidden_states.shape[0] >= 2:
         kw["_microbatches"] = microbatch_slices(hidden_states.shape[0])
-    out = model(hs, freqs_cis=fc, encoder_hidden_states=encoder_hidden_states, timestep=timestep,
-                encoder_attention_mask=encoder_attention_mask, skip_layer_mask=skip_layer_mask,
-                skip_layer_strategy=skip_layer_strategy, latent_shape=latent_shape, return_dict=False, **kw)
+    kw.pop("return_dict", None)
+    # (with ``model.forward`` rebound to this function, the shard goes to the class's own forward)
+    run = (lambda *a, **k: type(model).forward(model, *a, **k)) if _unbound else model
+    out = run(hs, freqs_cis=fc, encoder_hidden_states=encoder_hidden_states, timestep=timestep,
+              encoder_attention_mask=encoder_attention_mask, skip_layer_mask=skip_layer_mask,
+              skip_layer_strategy=skip_layer_strategy, latent_shape=latent_shape, return_dict=False, **kw)
+    if out[0] is None:
+        return [None]
     return (gather_tokens(out[0], group),)
 
 

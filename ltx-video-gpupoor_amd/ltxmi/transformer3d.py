@@ -228,6 +228,12 @@ class Transformer3DModel(nn.Module):
         B = hidden_states.shape[0]
         on_gpu = hidden_states.is_cuda
         streams = None
+        # Everything that is created lazily and SHARED between the slices is created here, on the main stream, before the
+        # side streams fork from it: the packed projection weights (``Attention._pack`` caches whatever the first caller
+        # built -- on a fresh model, or after a reload / LoRA merge invalidated the packs, slice 1 on stream 1 would
+        # otherwise take slice 0's cache entry while stream 0's torch.cat may still be writing it).
+        for block in self.transformer_blocks:
+            block.prepare_shared_state()
         if on_gpu:
             main = torch.cuda.current_stream()
             key = (hidden_states.device, len(slices))
@@ -390,6 +396,10 @@ class Transformer3DModel(nn.Module):
                           skip_layer_strategy=skip_layer_strategy)
                     if ltxv_model is not None and ltxv_model._interrupt:
                         return [None]
+
+        for block in self.transformer_blocks:                                    # this forward's hand-over ends here
+            if getattr(block, "attn2", None) is not None:
+                block.attn2.__dict__.pop("_text_kv_ready", None)
 
         # 3. output: LayerNorm (no affine, 1e-6) -> (1 + scale) x + shift -> proj_out (:489-503)
         T1 = embedded_timestep.shape[1]

@@ -89,7 +89,9 @@ def sdpa_nhd(q, k, v, attention_mask=None, head_chunk=8):
     F.scaled_dot_product_attention) and chunked over heads to bound memory."""
     B, Lq, H, dh = q.shape
     scale = 1.0 / math.sqrt(dh)
-    out = torch.empty(B, Lq, H, v.shape[-1], dtype=q.dtype)
+    out = torch.empty(B, Lq, H, v.shape[-1], dtype=q.dtype, device=q.device)
+    # bound the fp32 score block (and its softmax copy) to ~3 GB: at N = 13 376 x B 3 eight heads would be 17 GB
+    head_chunk = max(1, min(head_chunk, int(3e9 // max(1, B * Lq * k.shape[1] * 4))))
     for h0 in range(0, H, head_chunk):
         h1 = min(H, h0 + head_chunk)
         qq = q[:, :, h0:h1].permute(0, 2, 1, 3).float()

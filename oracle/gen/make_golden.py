@@ -760,7 +760,291 @@ def g10c():
     save("g10c_decoder_variants", t, dict(cfg=cfg, noise_shapes=[list(s) for s in shapes]))
 
 
-CASES = {"g10c": g10c, "g7": g7, "g14": g14, "g13": g13, "g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
+@torch.no_grad()
+def g0():
+    """G0: the reference's own ``get_timestep_embedding`` (ltx_video/models/transformers/embeddings.py:10-50) on the
+    timestep values the path feeds it (scaled by timestep_scale_multiplier = 1000, fractional, zero, per-frame lists) in
+    the two parameterisations used: (256, flip, shift 0) of PixArtAlphaCombinedTimestepSizeEmbeddings, and the function's
+    defaults.  Pins oracle/leaves.py::get_timestep_embedding (CPU) and the ltxmi_timestep_embedding_bf16 kernel (GPU)."""
+    print("G0 sinusoidal timestep embedding")
+    from ltx_video.models.transformers.embeddings import get_timestep_embedding
+    g = torch.Generator().manual_seed(5)
+    ts = torch.cat([torch.tensor([0.0, 1.0, 1000.0, 999.0, 700.0, 50.0, 0.5, 123.456]),
+                    1000.0 * torch.rand(24, generator=g)])
+    t = {"timesteps": ts,
+         "emb_256_flip_shift0": get_timestep_embedding(ts, 256, flip_sin_to_cos=True, downscale_freq_shift=0.0),
+         "emb_64_defaults": get_timestep_embedding(ts, 64),
+         "emb_33_odd_scale2": get_timestep_embedding(ts, 33, flip_sin_to_cos=False, downscale_freq_shift=1, scale=2.0,
+                                                     max_period=1000)}
+    save("g0_timestep_embedding", t, {})
+
+
+@torch.no_grad()
+def g15():
+    """G15: the reference's own ``LTXMultiScalePipeline.__call__`` (pipeline_ltx_video.py:1741-1905) called with EXACTLY the
+    keyword arguments of ``LTXV.generate`` (ltxv.py:420-445): the YAML dict spread into the call (every key of
+    configs/ltxv-13b-0.9.7-dev.yaml except ``stg_mode``, which ltxv.py:405 deletes; the per-step tables shortened to the
+    tiny model's 2 blocks and a handful of steps), string prompts, ``output_type="pt"``, ``VAE_tile_size``, ``device``,
+    ``callback`` -- fp32 on the CPU, on instances made without the diffusers base-class __init__.  The T5 pair is the
+    test double of tests/fake_t5.py (the text encoder is outside the path; the same double drives the product in the
+    tests).  DiT = G7's (same config and seed: its weights are in g7_pipeline_call); VAE decoder and latent upsampler
+    weights come from the oracle's seeded initialisers (too large to commit: regenerated in the tests, fingerprints in
+    the manifest).  Recorded: every noise draw, the pass-1 latents, the upsampled + AdaIN latents, the callback trace and
+    the final video."""
+    print("G15 LTXMultiScalePipeline.__call__ with ltxv.py's keyword arguments")
+    import contextlib
+    import tempfile
+    ref_shims.install_pipeline_leaves()
+    import ltx_video.pipelines.pipeline_ltx_video as ref_pl
+    import ltx_video.models.autoencoders.latent_upsampler as ref_lu
+    from oracle import upsampler as ou, vae as ov
+    from tests.fake_t5 import FakeTextEncoder, FakeTokenizer
+
+    class _StaysOnCpu(torch.Tensor):
+        def to(self, *a, **k):
+            a = tuple(x for x in a if not (isinstance(x, str) and x.startswith("cuda")))
+            return torch.Tensor.to(self.as_subclass(torch.Tensor), *a, **k) if (a or k) else self.as_subclass(torch.Tensor)
+
+    cfg = dict(TINY_DIT, in_channels=128, out_channels=128, num_attention_heads=2, attention_head_dim=64,
+               cross_attention_dim=128, caption_channels=128)
+    model = build_dit(cfg, 95)                                  # = G7's model
+    model.in_channels = cfg["in_channels"]
+    # the reference's demo config (0.9.5+-style decoder); the encoder (unused: no conditioning media) stays at 8 base
+    # channels, but its block list must be the real one: the pipeline derives its (8, 32, 32) scale factors from it
+    vcfg = jsonable(dict(ref_cva.create_video_autoencoder_demo_config(latent_channels=128), decoder_base_channels=64,
+                         encoder_base_channels=8))
+    vsd = ov.init_state_dict(vcfg, seed=150)
+    std, mean = vsd["per_channel_statistics.std-of-means"], vsd["per_channel_statistics.mean-of-means"]
+    vae = ref_cva.CausalVideoAutoencoder.from_config(jsonable(vcfg)).eval()
+    missing, unexpected = vae.decoder.load_state_dict({k[len("decoder."):]: v for k, v in vsd.items()
+                                                       if k.startswith("decoder.")}, strict=False)
+    assert not unexpected and all("timestep_scale_multiplier" in k or "last_" in k for k in missing), (missing, unexpected)
+    vae.register_buffer("std_of_means", std)
+    vae.register_buffer("mean_of_means", mean)
+    ucfg = dict(in_channels=128, mid_channels=64, num_blocks_per_stage=1, dims=3, spatial_upsample=True,
+                temporal_upsample=False)
+    usd = ou.init_state_dict(ucfg, seed=152)
+    ups = ref_lu.LatentUpsampler.from_config(ucfg).eval()
+    ups.load_state_dict(usd)
+
+    draws = []
+
+    def logged_randn(shp, generator=None, device=None, dtype=None, layout=None):
+        n = ref_shims.randn_tensor(shp, generator=generator, device=device, dtype=dtype)
+        draws.append(n)
+        return n
+
+    ref_pl.randn_tensor = logged_randn
+    pipe = object.__new__(ref_pl.LTXVideoPipeline)
+    pipe.transformer, pipe.vae = model, vae
+    pipe.patchifier = ref_sp.SymmetricPatchifier(patch_size=1)
+    pipe.scheduler = ref_rf.RectifiedFlowScheduler(sampler="Uniform", shifting="SD3", base_resolution=None,
+                                                   target_shift_terminal=0.1)
+    pipe.tokenizer, pipe.text_encoder = FakeTokenizer(), FakeTextEncoder(cfg["caption_channels"], seed=153).eval()
+    pipe.vae_scale_factor, pipe.video_scale_factor = 32, 8
+    pipe.allowed_inference_steps = None
+    pipe._execution_device = torch.device("cpu")
+    pipe.image_processor = ref_shims.VaeImageProcessor(vae_scale_factor=32)
+
+    class _Bar:
+        def update(self, *a):
+            pass
+
+    pipe.progress_bar = lambda total=None: contextlib.nullcontext(_Bar())
+    enc = pipe.encode_prompt
+
+    def encode_keeping_the_mask_on_the_cpu(*a, **k):            # __call__ :1041 does negative_prompt_attention_mask.to("cuda")
+        pe, pm, ne, nm = enc(*a, **k)
+        rec["prompt_embeds"], rec["prompt_attention_mask"] = pe.float(), pm.float()
+        rec["negative_prompt_embeds"], rec["negative_prompt_attention_mask"] = ne.float(), nm.float()
+        return pe, pm, ne, nm.as_subclass(_StaysOnCpu)
+
+    pipe.encode_prompt = encode_keeping_the_mask_on_the_cpu
+    ms = ref_pl.LTXMultiScalePipeline(pipe, ups)
+    rec = {}
+    up = ms._upsample_latents
+
+    def rec_upsample(upsampler, latents):
+        out = up(upsampler, latents)
+        rec["pass1_latents"], rec["upsampled"] = latents.float(), out.float()
+        return out
+
+    ms._upsample_latents = rec_upsample
+    trace = []
+
+    def callback(i, preview, start, **kw):
+        trace.append([int(i), None if preview is None else list(preview.shape), bool(start), int(kw.get("pass_no", 0)),
+                      kw.get("override_num_inference_steps")])
+        if preview is not None:                                 # the latents after step i of that pass, (c, f, h, w)
+            rec[f"preview.{kw.get('pass_no', 0)}.{i}"] = preview.float().clone()
+
+    # ltxv.py:309-312: pipeline_config = yaml.safe_load(the dev YAML); :404-405: stg_mode read and deleted.  Same keys; the
+    # guidance tables keep their form (lists over guidance_timesteps, per-entry skip lists) at the tiny model's size.
+    pipeline_config = {
+        "pipeline_type": "multi-scale", "checkpoint_path": "ltxv-13b-0.9.7-dev.safetensors", "downscale_factor": 0.6666666,
+        "spatial_upscaler_model_path": "ltxv-spatial-upscaler-0.9.7.safetensors", "decode_timestep": 0.05,
+        "decode_noise_scale": 0.025, "text_encoder_model_name_or_path": "PixArt-alpha/PixArt-XL-2-1024-MS",
+        "precision": "bfloat16", "sampler": "from_checkpoint", "prompt_enhancement_words_threshold": 120,
+        "prompt_enhancer_image_caption_model_name_or_path": "MiaoshouAI/Florence-2-large-PromptGen-v2.0",
+        "prompt_enhancer_llm_model_name_or_path": "unsloth/Llama-3.2-3B-Instruct", "stochastic_sampling": False,
+        "first_pass": {"guidance_scale": [1, 1, 6, 8, 6, 1, 1], "stg_scale": [0, 0, 4, 4, 4, 2, 1],
+                       "rescaling_scale": [1, 1, 0.5, 0.5, 1, 1, 1],
+                       "guidance_timesteps": [1.0, 0.9, 0.75, 0.6, 0.4, 0.2, 0.1],      # (spread over the 5-step schedule)
+                       "skip_block_list": [[], [1], [0, 1], [1], [1], [0], [1]], "num_inference_steps": 30,
+                       "skip_final_inference_steps": 1, "cfg_star_rescale": True},
+        "second_pass": {"guidance_scale": [1], "stg_scale": [1], "rescaling_scale": [1], "guidance_timesteps": [1.0],
+                        "skip_block_list": [1], "num_inference_steps": 30, "skip_initial_inference_steps": 3,
+                        "cfg_star_rescale": True},
+    }
+    call = dict(num_inference_steps1=6, num_inference_steps2=5, output_type="pt", callback_on_step_end=None,
+                height=96, width=192, num_frames=9, frame_rate=30,
+                prompt="a red fox runs through fresh snow at dawn", prompt_attention_mask=None,
+                negative_prompt="worst quality, blurry, jittery", negative_prompt_attention_mask=None,
+                media_items=None, strength=1.0, conditioning_items=None, is_video=True, vae_per_channel_normalize=True,
+                image_cond_noise_scale=0.15, mixed_precision=False, VAE_tile_size=(0, 0), device="cpu")
+    holder = types.SimpleNamespace(_interrupt=False)
+    like_draws, plain_randn_like = [], torch.randn_like
+
+    def logged_randn_like(x, *a, **k):                         # recorded as drawn (other code shares the global RNG)
+        n = plain_randn_like(x, *a, **k)
+        like_draws.append(n.clone())
+        return n
+
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:                 # __call__ :1290 writes "lala.pt" into the working directory
+        os.chdir(tmp)
+        try:
+            torch.manual_seed(154)                             # the decode noise is torch.randn_like: the global RNG (:1271)
+            torch.randn_like = logged_randn_like
+            images = ms(**json.loads(json.dumps(pipeline_config)), ltxv_model=holder,
+                        skip_layer_strategy=SkipLayerStrategy.AttentionValues,
+                        generator=torch.Generator().manual_seed(155), callback=callback, **call)
+        finally:
+            torch.randn_like = plain_randn_like
+            os.chdir(cwd)
+    assert len(draws) == 2 and len(like_draws) == 1, [tuple(d.shape) for d in draws + like_draws]
+    t = dict(rec)
+    t["decode_noise"] = like_draws[0]
+    t["noise.0"], t["noise.1"] = draws
+    t["images"] = images.float()
+
+    def fingerprint(sd):
+        return float(sum(v.double().abs().sum() for v in sd.values()))
+
+    save("g15_multiscale_call", t, dict(
+        dit_cfg=cfg, dit_weights="g7_pipeline_call (w.*)", vae_cfg=jsonable(vcfg), vae_seed=150, upsampler_cfg=ucfg,
+        upsampler_seed=152, text_encoder_seed=153, vae_fingerprint=fingerprint(vsd), upsampler_fingerprint=fingerprint(usd),
+        pipeline_config=pipeline_config, call=call, skip_layer_strategy="AttentionValues", callback_trace=trace,
+        images_shape=list(images.shape)))
+
+
+def _sig_record(fn):
+    """names, kinds and defaults (repr; enum members by name) of a callable's parameters -- data about the reference's
+    interface, nothing of its code."""
+    import enum
+    import inspect
+    out = []
+    for prm in inspect.signature(fn).parameters.values():
+        d = None
+        if prm.default is not inspect.Parameter.empty:
+            v = prm.default
+            d = f"{type(v).__name__}.{v.name}" if isinstance(v, enum.Enum) else repr(v)
+        out.append({"name": prm.name, "kind": prm.kind.name, "has_default": prm.default is not inspect.Parameter.empty,
+                    "default": d})
+    return out
+
+
+def _sig_record_ast(path, func):
+    """The same record for a module that cannot be imported here (wan/distributed needs xfuser): parsed from the source
+    text with ``ast`` -- only the parameter list is read."""
+    import ast
+    with open(path) as f:
+        tree = ast.parse(f.read())
+    node = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == func)
+    a = node.args
+    pos = list(a.posonlyargs) + list(a.args)
+    defaults = [None] * (len(pos) - len(a.defaults)) + list(a.defaults)
+    out = []
+    for arg, d in zip(pos, defaults):
+        out.append({"name": arg.arg, "kind": "POSITIONAL_OR_KEYWORD", "has_default": d is not None,
+                    "default": None if d is None else ast.unparse(d)})
+    if a.vararg:
+        out.append({"name": a.vararg.arg, "kind": "VAR_POSITIONAL", "has_default": False, "default": None})
+    for arg, d in zip(a.kwonlyargs, a.kw_defaults):
+        out.append({"name": arg.arg, "kind": "KEYWORD_ONLY", "has_default": d is not None,
+                    "default": None if d is None else ast.unparse(d)})
+    if a.kwarg:
+        out.append({"name": a.kwarg.arg, "kind": "VAR_KEYWORD", "has_default": False, "default": None})
+    return out
+
+
+def signatures():
+    """``inspect.signature`` of every public entry point of the hot path, taken from the reference's own
+    objects, into tests/golden/signatures.json.  tests/test_host_logic.py compares the product's against it (same
+    names, order, kinds and defaults; only trailing keyword extras allowed)."""
+    print("signatures of the reference's entry points")
+    ref_shims.install_pipeline_leaves()
+    import ltx_video.pipelines.pipeline_ltx_video as ref_pl
+    import ltx_video.models.autoencoders.vae as ref_vae
+    import ltx_video.models.autoencoders.latent_upsampler as ref_up
+    import wan.modules.attention as ref_wa
+    pl, ms = ref_pl.LTXVideoPipeline, ref_pl.LTXMultiScalePipeline
+    table = {
+        "Transformer3DModel.__init__": ref_t3.Transformer3DModel.__init__,
+        "Transformer3DModel.forward": ref_t3.Transformer3DModel.forward,
+        "Transformer3DModel.precompute_freqs_cis": ref_t3.Transformer3DModel.precompute_freqs_cis,
+        "Transformer3DModel.create_skip_layer_mask": ref_t3.Transformer3DModel.create_skip_layer_mask,
+        "BasicTransformerBlock.forward": ref_attn.BasicTransformerBlock.forward,
+        "Attention.set_processor": ref_attn.Attention.set_processor,
+        "Attention.forward": ref_attn.Attention.forward,
+        "AttnProcessor2_0.__call__": ref_attn.AttnProcessor2_0.__call__,
+        "pay_attention": ref_wa.pay_attention,
+        "CausalVideoAutoencoder.decode": ref_cva.CausalVideoAutoencoder.decode,
+        "CausalVideoAutoencoder.encode": ref_cva.CausalVideoAutoencoder.encode,
+        "CausalVideoAutoencoder.enable_z_tiling": ref_cva.CausalVideoAutoencoder.enable_z_tiling,
+        "CausalVideoAutoencoder.set_tiling_params": ref_cva.CausalVideoAutoencoder.set_tiling_params,
+        "CausalVideoAutoencoder.get_VAE_tile_size": ref_cva.CausalVideoAutoencoder.get_VAE_tile_size,
+        "Decoder.forward": ref_cva.Decoder.forward,
+        "CausalConv3d.forward": ref_cc3.CausalConv3d.forward,
+        "vae_decode": ref_ve.vae_decode,
+        "vae_encode": ref_ve.vae_encode,
+        "un_normalize_latents": ref_ve.un_normalize_latents,
+        "normalize_latents": ref_ve.normalize_latents,
+        "latent_to_pixel_coords": ref_ve.latent_to_pixel_coords,
+        "SymmetricPatchifier.patchify": ref_sp.SymmetricPatchifier.patchify,
+        "SymmetricPatchifier.unpatchify": ref_sp.SymmetricPatchifier.unpatchify,
+        "RectifiedFlowScheduler.__init__": ref_rf.RectifiedFlowScheduler.__init__,
+        "RectifiedFlowScheduler.set_timesteps": ref_rf.RectifiedFlowScheduler.set_timesteps,
+        "RectifiedFlowScheduler.step": ref_rf.RectifiedFlowScheduler.step,
+        "RectifiedFlowScheduler.add_noise": ref_rf.RectifiedFlowScheduler.add_noise,
+        "RectifiedFlowScheduler.scale_model_input": ref_rf.RectifiedFlowScheduler.scale_model_input,
+        "LTXVideoPipeline.__init__": pl.__init__,
+        "LTXVideoPipeline.__call__": pl.__call__,
+        "LTXVideoPipeline.encode_prompt": pl.encode_prompt,
+        "LTXVideoPipeline.check_inputs": pl.check_inputs,
+        "LTXVideoPipeline.prepare_latents": pl.prepare_latents,
+        "LTXVideoPipeline.prepare_conditioning": pl.prepare_conditioning,
+        "LTXVideoPipeline.resize_tensor": pl.resize_tensor,
+        "LTXMultiScalePipeline.__init__": ms.__init__,
+        "LTXMultiScalePipeline.__call__": ms.__call__,
+        "LTXMultiScalePipeline._upsample_latents": ms._upsample_latents,
+        "retrieve_timesteps": ref_pl.retrieve_timesteps,
+        "adain_filter_latent": ref_pl.adain_filter_latent,
+        "ConditioningItem": ref_pl.ConditioningItem,
+        "LatentUpsampler.__init__": ref_up.LatentUpsampler.__init__,
+        "LatentUpsampler.forward": ref_up.LatentUpsampler.forward,
+    }
+    rec = {k: _sig_record(v) for k, v in table.items()}
+    usp = ref_shims.REFERENCE_ROOT + "/wan/distributed/xdit_context_parallel.py"
+    rec["wan.usp_dit_forward"] = _sig_record_ast(usp, "usp_dit_forward")
+    rec["wan.usp_attn_forward"] = _sig_record_ast(usp, "usp_attn_forward")
+    rec["wan.shard_model"] = _sig_record_ast(ref_shims.REFERENCE_ROOT + "/wan/distributed/fsdp.py", "shard_model")
+    with open(os.path.join(OUT, "signatures.json"), "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print(f"  signatures.json: {len(rec)} entry points")
+
+
+CASES = {"signatures": signatures, "g0": g0, "g15": g15, "g10c": g10c, "g7": g7, "g14": g14, "g13": g13, "g1": g1_g2, "g3": g3_g4_g5, "g6": g6, "g8": g8_g9, "g10": g10, "g11": g11, "g12": g12}
 
 
 def main():

@@ -142,7 +142,10 @@ class PixArtAlphaCombinedTimestepSizeEmbeddings(nn.Module):
         self.timestep_embedder = TimestepEmbedding(256, embedding_dim)
 
     def forward(self, timestep, resolution, aspect_ratio, batch_size, hidden_dtype):
-        proj = _leaves().get_timestep_embedding(timestep, 256, flip_sin_to_cos=True, downscale_freq_shift=0.0)
+        # the sinusoid is the REFERENCE's own in-repo copy (ltx_video/models/transformers/embeddings.py:10-50, imports
+        # untouched), not the oracle's restatement: the goldens do not depend on oracle code here (G0 pins the two)
+        from ltx_video.models.transformers.embeddings import get_timestep_embedding
+        proj = get_timestep_embedding(timestep, 256, flip_sin_to_cos=True, downscale_freq_shift=0.0)
         return self.timestep_embedder(proj.to(dtype=hidden_dtype))
 
 
@@ -228,12 +231,29 @@ def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
     return torch.randn(tuple(shape), generator=generator, device=device, dtype=dtype)
 
 
+class VaeImageProcessor:
+    """diffusers.image_processor.VaeImageProcessor, the part the pipeline calls (pipeline_ltx_video.py:303, 1299):
+    ``postprocess(image, output_type)`` with do_normalize=True -- "latent" passes through, "pt" de-normalises
+    ``(x / 2 + 0.5).clamp(0, 1)`` (restated leaf, PARITY UNPINNED like the other diffusers leaves)."""
+
+    def __init__(self, vae_scale_factor=8, **kw):
+        self.vae_scale_factor = vae_scale_factor
+
+    @staticmethod
+    def postprocess(image, output_type="pil", do_denormalize=None):
+        if output_type == "latent":
+            return image
+        if output_type != "pt":
+            raise ValueError("only 'pt' / 'latent' are restated here (video tensors)")
+        return torch.stack([(image[i] / 2 + 0.5).clamp(0, 1) for i in range(image.shape[0])])
+
+
 def install_pipeline_leaves():
     """Extra inert leaves so that ``ltx_video.pipelines.pipeline_ltx_video`` imports: its
     static/helper methods (prepare_conditioning, denoising_step, add_noise_to_image_conditioning_latents,
     the latent upsampler bridge ...) are then callable with a light stand-in ``self``."""
     install()
-    _mod("diffusers.image_processor", VaeImageProcessor=_Dummy)
+    _mod("diffusers.image_processor", VaeImageProcessor=VaeImageProcessor)
     p = _mod("diffusers.pipelines")
     p.__path__ = []
     _mod("diffusers.pipelines.pipeline_utils", DiffusionPipeline=type("DiffusionPipeline", (), {}),

@@ -179,7 +179,21 @@ def stg_blend_grouped_(a, v, m_f32):
     return a
 
 
-NAMES = ["gemm", "norm_modulate", "rmsnorm_rope_", "attention_fuses_qnorm", "attention_kernel_id", "attention", "qkv_norm_rope_pack", "silu",
+def guidance_step_(noise_pred, latents, dt, guidance_scale, stg_scale, rescaling_scale, do_cfg, do_stg, do_rescale,
+                   workspace, cond_mask=None, t=0.0):
+    """CFG-star / STG / std-rescale + Euler (+ conditioning mask), in place on ``latents`` -- the arithmetic of the
+    oracle's guidance (pipeline_ltx_video.py:1183-1241, 1309-1342)."""
+    from oracle import sched
+    v = sched.guidance(noise_pred.float(), noise_pred.shape[0], guidance_scale, stg_scale, rescaling_scale,
+                       bool(do_cfg), bool(do_stg), bool(do_rescale))
+    new = latents.float() - dt * v
+    if cond_mask is not None:
+        new = torch.where((t - 1e-6 < 1.0 - cond_mask).unsqueeze(-1), new, latents.float())
+    latents.copy_(new.to(latents.dtype))
+    return latents
+
+
+NAMES = ["guidance_step_", "gemm", "norm_modulate", "rmsnorm_rope_", "attention_fuses_qnorm", "attention_kernel_id", "attention", "qkv_norm_rope_pack", "silu",
          "timestep_embedding", "stg_blend_", "stg_blend_grouped_", "rowsumsq_rstd"]
 
 

@@ -185,6 +185,109 @@ def _case_usp_interrupt_is_collective(rank, world):
     assert again[0] is not None and torch.equal(again[0], out[0])
 
 
+def _case_usp_first_forward_of_a_fresh_model(rank, world):
+    """the overlap mode (two micro-batches of rows, a stream each) as the VERY FIRST forward of a freshly
+    loaded model, and again after the packed weights were invalidated (reload / LoRA merge): everything the slices share
+    is built before the streams fork (BasicTransformerBlock.prepare_shared_state), so the result is the plain loop's.
+    (On the CPU the slices run one after the other -- the GPU twin of this case is in tests/test_gpu_model.py.)  With
+    step-invariant caching off, the stacked text K/V of the forward serve EVERY slice: no per-layer K/V GEMM is left."""
+    from ltxmi import distributed as sp
+    ltxmi, m, x, fc, kw = _dit_setup(False)
+    _, m2, _, _, _ = _dit_setup(False)
+    with torch.no_grad():
+        sp.enable_sequence_parallel(m)                                               # overlap on: the first forward ever
+        out = sp.usp_dit_forward(m, x.clone(), fc, **kw)[0]
+        sp.enable_sequence_parallel(m2, overlap=False)
+        plain = sp.usp_dit_forward(m2, x.clone(), fc, **kw)[0]
+        assert torch.equal(out, plain)
+        for blk in m.transformer_blocks:
+            blk.attn1.invalidate_packed()
+            blk.attn2.invalidate_packed()
+        assert torch.equal(sp.usp_dit_forward(m, x.clone(), fc, **kw)[0], plain)
+        # caching off: the stacked projection of all layers' text K/V, handed to the blocks per slice
+        from ltxmi import ops
+        ltxmi.set_step_invariant_caching(False)
+        try:
+            D = m.inner_dim
+            per_layer = []
+            real = ops.gemm
+
+            def counting(a, w, *args, **kws):
+                if tuple(w.shape) == (2 * D, D):
+                    per_layer.append(tuple(a.shape))
+                return real(a, w, *args, **kws)
+
+            ops.gemm = counting
+            off = sp.usp_dit_forward(m, x.clone(), fc, **kw)[0]
+            ops.gemm = real
+        finally:
+            ltxmi.set_step_invariant_caching(True)
+        assert torch.equal(off, plain)
+        assert per_layer == [], per_layer
+
+
+def _case_usp_interrupt_on_the_last_forward(rank, world):
+    """an interrupt raised during the LAST forward of a generation is posted but never read (there is no
+    forward k + 1).  ``begin_generation`` drops it, so the next generation's first forward runs normally on every rank."""
+    from ltxmi import distributed as sp
+    ltxmi, m, x, fc, kw = _dit_setup(False)
+    sp.enable_sequence_parallel(m)
+
+    class Holder:
+        _interrupt = (rank == 1)
+
+    class Quiet:
+        _interrupt = False
+
+    with torch.no_grad():
+        out = sp.usp_dit_forward(m, x.clone(), fc, ltxv_model=Quiet(), **kw)
+        last = sp.usp_dit_forward(m, x.clone(), fc, ltxv_model=Holder(), **kw)        # raised in the generation's last forward
+        assert last[0] is not None
+        sp.begin_generation(m)                                                         # (the pipeline calls this)
+        new = sp.usp_dit_forward(m, x.clone(), fc, ltxv_model=Quiet(), **kw)
+    assert new[0] is not None and torch.equal(new[0], out[0])
+
+
+def _case_pipeline_runs_sequence_parallel_unchanged(rank, world):
+    """``enable_sequence_parallel(model, bind_forward=True)`` (the reference's MethodType pattern, wan/text2video.py):
+    ``ltxmi.LTXVideoPipeline.__call__`` -- the reference's signature -- then denoises with the tokens sharded over the
+    ranks without knowing it: same latents as the single-rank loop up to matmul blocking, identical on every rank."""
+    from ltxmi import distributed as sp
+    ltxmi, m, x, fc, kw = _dit_setup(False)
+    g = torch.Generator().manual_seed(9)
+    T = 12
+    pos, neg = torch.randn(1, T, 128, generator=g), torch.randn(1, T, 128, generator=g)
+    pmask, nmask = torch.ones(1, T), torch.ones(1, T)
+    pmask[:, 8:] = 0
+    nmask[:, 3:] = 0
+    noise = torch.randn(1, 2 * 2 * 4, 128, generator=g)
+    args = dict(height=64, width=128, num_frames=9, frame_rate=25.0, prompt_embeds=pos, prompt_attention_mask=pmask,
+                negative_prompt_embeds=neg, negative_prompt_attention_mask=nmask, num_inference_steps=2, guidance_scale=3.0,
+                stg_scale=1.0, rescaling_scale=0.7, skip_block_list=[1],
+                skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, latents=noise, output_type="latent",
+                is_video=True, joint_pass=True, return_dict=False)
+    pipe = ltxmi.LTXVideoPipeline(transformer=m, scheduler=ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1))
+    single = pipe(**args)[0]
+    sp.enable_sequence_parallel(m, bind_forward=True)
+    seen = []
+    sharded = pipe(callback=lambda i, lat, start, **k: seen.append(i), **args)[0]
+    assert seen == [-1, 0, 1]
+    assert sharded.shape == single.shape == (1, 128, 2, 2, 4)
+    err = float((sharded.float() - single.float()).norm() / single.float().norm())
+    assert err < 5e-3, err
+    both = [torch.empty_like(sharded) for _ in range(world)]
+    dist.all_gather(both, sharded.contiguous())
+    assert all(torch.equal(b, both[0]) for b in both)
+    # a cancel raised on one rank: agreed one step later, and the pipeline returns None on EVERY rank
+    holder = type("H", (), {"_interrupt": rank == 0})()
+    assert pipe(ltxv_model=holder, **dict(args, num_inference_steps=3)) is None
+    # ... and the next generation is not affected by the flag the cancelled one posted
+    again = pipe(**args)[0]
+    assert torch.equal(again, sharded)
+    sp.disable_sequence_parallel(m)
+    assert torch.equal(pipe(**args)[0], single)
+
+
 def _case_exchange_tiles(rank, world):
     """The two-phase tile exchange of tile_parallel_vae_decode: every rank decodes ALL its tiles (n = rank mod P) before
     the one collective; uneven tile counts and sizes; the tiles come back as they were written."""
@@ -241,3 +344,15 @@ def test_exchange_tiles_two_phase_world2():
 
 def test_exchange_tiles_world3():
     _run("_case_exchange_tiles", world=3)
+
+
+def test_usp_first_forward_of_a_fresh_model_world2():
+    _run("_case_usp_first_forward_of_a_fresh_model")
+
+
+def test_usp_interrupt_on_the_last_forward_world2():
+    _run("_case_usp_interrupt_on_the_last_forward")
+
+
+def test_pipeline_runs_sequence_parallel_unchanged_world2():
+    _run("_case_pipeline_runs_sequence_parallel_unchanged")

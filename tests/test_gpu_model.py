@@ -40,7 +40,9 @@ def assert_parity(out, truth, eager, what):
     assert torch.isfinite(out.float()).all(), f"{what}: non-finite output"
     e_ours, e_ref = rel(out, truth), rel(eager, truth)
     m_ours, m_ref = maxrel(out, truth), maxrel(eager, truth)
-    print(f"{what}: rel L2 ours {e_ours:.3e} / reference-bf16-eager {e_ref:.3e};  max err / range ours {m_ours:.3e} / eager {m_ref:.3e}")
+    e_direct = rel(out, eager)            # ours against the bf16 eager rendering itself (two bf16 renderings: not asserted)
+    print(f"{what}: rel L2 vs fp32 oracle: ours {e_ours:.3e} / reference-bf16-eager {e_ref:.3e};  ours vs bf16-eager directly "
+          f"{e_direct:.3e};  max err / range ours {m_ours:.3e} / eager {m_ref:.3e}")
     assert e_ours <= e_ref + RTOL, (what, e_ours, e_ref)
     assert m_ours <= 1.5 * m_ref + 1e-2, (what, m_ours, m_ref)
     return e_ours, e_ref
@@ -74,18 +76,24 @@ def build_model(cfg, sd32):
     return m.to(device=DEV, dtype=BF).eval()
 
 
-def run_oracles(cfg, sd32, x, enc, mask, ts, frac, grid, **kw):
+def run_oracles(cfg, sd32, x, enc, mask, ts, frac, grid, truth_device="cpu", eager_device="cpu", **kw):
+    """(fp32 truth, the reference's bf16 eager rendering) from the oracle's plain-PyTorch restatement.  ``*_device``: the
+    oracle is device-agnostic torch code; for the sizes the host cannot turn around in a test (config 3 at full depth) it
+    is run on the GPU -- rocBLAS / eager torch kernels, i.e. the reference's own eager path on this hardware -- and
+    still shares nothing with libltxmi."""
     from oracle import dit
-    fc32 = dit.precompute_freqs_cis(frac, cfg, torch.float32)
-    truth = dit.transformer3d_forward(sd32, cfg, x.float(), fc32, enc.float(), ts, encoder_attention_mask=mask,
-                                      latent_shape=grid, **kw)
-    sdb = {k: v.to(BF) for k, v in sd32.items()}
-    fcb = dit.precompute_freqs_cis(frac, cfg, BF)
-    if "skip_layer_mask" in kw and kw["skip_layer_mask"] is not None:
-        kw = dict(kw, skip_layer_mask=kw["skip_layer_mask"].to(BF))
-    eager = dit.transformer3d_forward(sdb, cfg, x, fcb, enc, ts, encoder_attention_mask=mask,
-                                      latent_shape=grid, **kw)
-    return truth, eager
+
+    def one(dtype, device):
+        sd = {k: v.to(device=device, dtype=dtype) for k, v in sd32.items()}
+        fc = tuple(t.to(device) for t in dit.precompute_freqs_cis(frac, cfg, dtype))
+        k2 = dict(kw)
+        if k2.get("skip_layer_mask") is not None:
+            k2["skip_layer_mask"] = k2["skip_layer_mask"].to(device=device, dtype=dtype)
+        out = dit.transformer3d_forward(sd, cfg, x.to(device=device, dtype=dtype), fc, enc.to(device=device, dtype=dtype),
+                                        ts.to(device), encoder_attention_mask=mask.to(device), latent_shape=grid, **k2)
+        return out.cpu()
+
+    return one(torch.float32, truth_device), one(BF, eager_device)
 
 
 class _Holder:
@@ -341,6 +349,62 @@ def test_transformer_2b_full_depth():
     full = m(x2.to(DEV).clone(), **kw)[0]
     dedup = m(x2.to(DEV).clone(), stg_alias_blocks=19, **kw)[0]
     assert torch.equal(full, dedup)
+
+
+CONFIG3_GRID = (16, 22, 38)           # BASELINE config 3: 1216 x 704 x 121 -> 13 376 latent tokens
+
+
+def _config3_case(layers, seed):
+    """B_eff 3 (CFG + STG rows), per-token timesteps with the first latent frame conditioned (t = 0 there: the i2v form,
+    pipeline_ltx_video.py:1145-1150), T = 256 text tokens at the 2B widths."""
+    cfg, sd32, x, enc, mask, ts, frac = dit_case(32, 64, layers, CONFIG3_GRID, 3, 256, caption=4096, seed=seed, per_token=True)
+    assert x.shape == (3, 13376, 128) and ts.shape == (3, 13376) and float(ts[:, :22 * 38].max()) == 0.0
+    return cfg, sd32, x, enc, mask, ts, frac
+
+
+def test_transformer_config3_one_block_full_size():
+    """Config 3 on ONE GPU, one block: N = 13 376 tokens x B_eff 3 with per-token (per-frame) timesteps through one
+    BasicTransformerBlock + embeddings + output head (transformer3d.py:420-425 reshapes the timestep to [B, F], the AdaLN
+    tables then differ per frame) against the fp32 oracle run on the host (~9 TFLOP) and the bf16 eager rendering (the
+    oracle in bf16 on the device: eager torch kernels)."""
+    import ltxmi
+    from oracle import dit
+    cfg, sd32, x, enc, mask, ts, frac = _config3_case(1, seed=36)
+    skip = dit.create_skip_layer_mask(1, 1, 3, 2, [0], torch.float32)
+    truth, eager = run_oracles(cfg, sd32, x, enc, mask, ts, frac, CONFIG3_GRID, eager_device=DEV, skip_layer_mask=skip,
+                               skip_layer_strategy=dit.ATTENTION_VALUES)
+    m = build_model(cfg, sd32)
+    fc = m.precompute_freqs_cis(frac.to(DEV))
+    out = m(x.to(DEV), freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV),
+            timestep=ts.to(DEV), skip_layer_mask=m.create_skip_layer_mask(1, 3, 2, [0]),
+            skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=CONFIG3_GRID,
+            ltxv_model=_Holder(), return_dict=False)[0]
+    assert out.shape == (3, 13376, 128)
+    assert_parity(out, truth, eager, "config 3: 2B width, 1 block, N 13376, B_eff 3, per-token timesteps")
+
+
+def test_transformer_config3_full_depth_full_size():
+    """Config 3 on ONE GPU, the whole model: 28 layers at N = 13 376 x B_eff 3, per-token timesteps, STG row perturbed from
+    block 19 -- the workload ``bench.py``'s ``config3_step_1gpu`` leg times, and the N = 1 anchor of the 1 -> 8 curve.  The
+    two oracle runs (fp32 truth, bf16 eager: ~0.5 PFLOP each) are far beyond the host, so the oracle's PyTorch code runs
+    on the device in fp32 / bf16 (rocBLAS + eager kernels); the bound is the usual one: our error against the fp32 result
+    may not exceed the eager bf16 path's by more than 2e-3."""
+    import ltxmi
+    from oracle import dit
+    cfg, sd32, x, enc, mask, ts, frac = _config3_case(28, seed=46)
+    skip = dit.create_skip_layer_mask(28, 1, 3, 2, [19], torch.float32)
+    truth, eager = run_oracles(cfg, sd32, x, enc, mask, ts, frac, CONFIG3_GRID, truth_device=DEV, eager_device=DEV,
+                               skip_layer_mask=skip, skip_layer_strategy=dit.ATTENTION_VALUES)
+    torch.cuda.empty_cache()
+    m = build_model(cfg, sd32)
+    del sd32
+    fc = m.precompute_freqs_cis(frac.to(DEV))
+    out = m(x.to(DEV), freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV),
+            timestep=ts.to(DEV), skip_layer_mask=m.create_skip_layer_mask(1, 3, 2, [19]),
+            skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, latent_shape=CONFIG3_GRID,
+            ltxv_model=_Holder(), return_dict=False)[0]
+    assert out.shape == (3, 13376, 128)
+    assert_parity(out, truth, eager, "config 3: 2B, 28 layers, N 13376, B_eff 3, per-token timesteps")
 
 
 # ------------------------------------------------------------------------------- VAE
@@ -795,11 +859,13 @@ def test_pipeline_config1_two_steps():
                          [skip_blocks] * steps, BF)
 
     m = build_model(cfg, sd32)
-    pipe = ltxmi.LTXVideoPipeline(m, ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1))
-    out = pipe(height=256, width=256, num_frames=9, prompt_embeds=pos.to(DEV), prompt_attention_mask=pmask.to(DEV),
+    pipe = ltxmi.LTXVideoPipeline(transformer=m, scheduler=ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1))
+    out = pipe(height=256, width=256, num_frames=9, frame_rate=25.0, prompt_embeds=pos.to(DEV),
+               prompt_attention_mask=pmask.to(DEV),
                negative_prompt_embeds=neg.to(DEV), negative_prompt_attention_mask=nmask.to(DEV),
                num_inference_steps=steps, guidance_scale=gs, stg_scale=stg, rescaling_scale=rs,
-               skip_block_list=skip_blocks, latents=lat0.to(DEV), output_type="latent")
+               skip_block_list=skip_blocks, latents=lat0.to(DEV), output_type="latent",
+               skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, is_video=True, joint_pass=True, latents_dtype=torch.float32)
     assert out.shape == truth.shape == (1, 128, f, h, w)
     torch.testing.assert_close(torch.tensor(pipe.scheduler.host_timesteps), tsch, rtol=1e-6, atol=1e-7)
     assert_parity(out, truth, eager, "pipeline config 1, 2 steps")
@@ -826,13 +892,16 @@ def test_pipeline_matches_the_references_own_call(golden, run):
                                                      kw["skip_block_list"], guidance_timesteps=kw.get("guidance_timesteps"))
     eager = _oracle_loop(sd32, cfg, t[run + "noise"], emb, msk, ts, (f, h, w), gs, stg, rs, skips, BF)
     m = build_model(cfg, sd32)
-    pipe = ltxmi.LTXVideoPipeline(m, ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1))
-    for k in ("skip_layer_strategy", "frame_rate"):
-        kw.pop(k, None)
+    pipe = ltxmi.LTXVideoPipeline(transformer=m, scheduler=ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1))
+    kw["skip_layer_strategy"] = ltxmi.SkipLayerStrategy[kw["skip_layer_strategy"]]
+    # exactly the keyword arguments the reference's own __call__ was run with (oracle/gen/make_golden.py g7), plus the
+    # recorded noise draw in place of the generator and fp32 latents (the reference ran in fp32 throughout)
     out = pipe(prompt_embeds=t["prompt_embeds"].to(BF).to(DEV), prompt_attention_mask=t["prompt_attention_mask"].to(DEV),
                negative_prompt_embeds=t["negative_prompt_embeds"].to(BF).to(DEV),
                negative_prompt_attention_mask=t["negative_prompt_attention_mask"].to(DEV),
-               latents=t[run + "noise"].to(DEV), output_type="latent", frame_rate=25.0, **kw)
+               latents=t[run + "noise"].to(DEV), output_type="latent", return_dict=False, is_video=True,
+               vae_per_channel_normalize=True, joint_pass=True, ltxv_model=types.SimpleNamespace(_interrupt=False),
+               latents_dtype=torch.float32, **kw)[0]
     torch.testing.assert_close(torch.tensor(pipe.scheduler.host_timesteps), ts, rtol=1e-6, atol=1e-7)
     assert out.shape == truth.shape
     assert_parity(out, truth, eager, f"product pipeline vs the reference's own __call__ ({run or 'config 1'})")
@@ -845,8 +914,8 @@ def test_prepare_conditioning_matches_oracle():
     from oracle import conditioning as oc, vae_encoder as oe
     cfg, sd = vae_case("b", with_encoder=True)
     v = build_vae(cfg, sd)
-    pipe = ltxmi.LTXVideoPipeline(types.SimpleNamespace(config=types.SimpleNamespace(causal_temporal_positioning=True)),
-                                  None, vae=v)
+    pipe = ltxmi.LTXVideoPipeline(transformer=types.SimpleNamespace(config=types.SimpleNamespace(causal_temporal_positioning=True)),
+                                  vae=v)
     H, W, F_ = 64, 96, 33
     g = torch.Generator().manual_seed(30)
     img, seq, single = [(torch.rand(1, 3, n, H, W, generator=g) * 2 - 1).to(BF) for n in (1, 17, 1)]
@@ -922,12 +991,13 @@ def test_pipeline_image_to_video_two_steps():
     (truth, n_extra), (eager, _) = oracle(torch.float32), oracle(BF)
 
     m = build_model(cfg, sd32)
-    pipe = ltxmi.LTXVideoPipeline(m, ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1),
+    pipe = ltxmi.LTXVideoPipeline(transformer=m, scheduler=ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1),
                                   vae=build_vae(vcfg, vsd))
-    out = pipe(height=H, width=W, num_frames=F_, prompt_embeds=pos.to(DEV), prompt_attention_mask=pmask.to(DEV),
+    out = pipe(height=H, width=W, num_frames=F_, frame_rate=25.0, prompt_embeds=pos.to(DEV),
+               prompt_attention_mask=pmask.to(DEV),
                negative_prompt_embeds=neg.to(DEV), negative_prompt_attention_mask=nmask.to(DEV),
                num_inference_steps=steps, guidance_scale=gs, stg_scale=stg, rescaling_scale=rs,
-               skip_block_list=skip_blocks, latents=lat0.to(DEV), output_type="latent",
+               skip_block_list=skip_blocks, latents=lat0.to(DEV), output_type="latent", skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, is_video=True, joint_pass=True, latents_dtype=torch.float32,
                conditioning_items=[ltxmi.ConditioningItem(mm.to(DEV), fr, s) for mm, fr, s in spec],
                image_cond_noise_scale=ns, sample_conditioning_posterior=False,
                generator=torch.Generator(device=DEV).manual_seed(41))
@@ -1011,11 +1081,12 @@ def test_multiscale_pipeline_two_passes():
     ups = ups.to(device=DEV, dtype=BF).eval()
     vae = types.SimpleNamespace(std_of_means=stats["per_channel_statistics.std-of-means"].to(DEV),
                                 mean_of_means=stats["per_channel_statistics.mean-of-means"].to(DEV))
-    vp = ltxmi.LTXVideoPipeline(m, ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1), vae=vae)
+    vp = ltxmi.LTXVideoPipeline(transformer=m, scheduler=ltxmi.RectifiedFlowScheduler(shifting="SD3", target_shift_terminal=0.1), vae=vae)
     ms = ltxmi.LTXMultiScalePipeline(vp, ups)
-    out = ms(0.5, first, second, height=128, width=192, num_frames=9, prompt_embeds=pos.to(DEV),
+    out = ms(0.5, first, second, height=128, width=192, num_frames=9, frame_rate=25.0, prompt_embeds=pos.to(DEV),
              prompt_attention_mask=pmask.to(DEV), negative_prompt_embeds=neg.to(DEV),
              negative_prompt_attention_mask=nmask.to(DEV), output_type="latent",
+             skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, is_video=True, latents_dtype=torch.float32,
              generator=torch.Generator(device=DEV).manual_seed(51))
     assert out.shape == truth.shape == shape2
     torch.testing.assert_close(torch.tensor(vp.scheduler.host_timesteps), ts2, rtol=1e-6, atol=1e-7)
@@ -1026,12 +1097,89 @@ def test_multiscale_pipeline_two_passes():
     assert torch.isfinite(out.float()).all() and e <= e_ref + 5 * RTOL
     # the exact eliminations (rows whose guidance scale is zero at a step; the STG row before its first
     # skipped block) do not change a single bit
-    plain = ms(0.5, first, second, height=128, width=192, num_frames=9, prompt_embeds=pos.to(DEV),
+    plain = ms(0.5, first, second, height=128, width=192, num_frames=9, frame_rate=25.0, prompt_embeds=pos.to(DEV),
                prompt_attention_mask=pmask.to(DEV), negative_prompt_embeds=neg.to(DEV),
                negative_prompt_attention_mask=nmask.to(DEV), output_type="latent",
+               skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, is_video=True, latents_dtype=torch.float32,
                generator=torch.Generator(device=DEV).manual_seed(51), stg_row_dedup=False,
                dead_row_elimination=False)
     assert torch.equal(plain, out)
+
+
+def test_ltxv_generate_call_replayed_through_the_product(golden):
+    """The drop-in boundary, end to end: the keyword arguments of ``LTXV.generate``'s pipeline call (ltxv.py:420-445 -- the
+    YAML dict spread into the call, string prompts, ``output_type="pt"``, ``VAE_tile_size``, ``device``, ``callback`` ...) go
+    UNCHANGED into ``ltxmi.LTXMultiScalePipeline`` and the result is compared with what the reference's own
+    ``LTXMultiScalePipeline.__call__`` produced for them (golden G15, fp32 on the CPU), within what the reference's bf16
+    eager path manages (the oracle's two-pass restatement, itself pinned to G15 by tests/test_oracle_golden.py, run in
+    bf16).  The noise draws are the recorded ones (the reference drew them on the CPU); the T5 pair is the same test
+    double that drove the reference."""
+    import ltxmi
+    from unittest import mock
+    from oracle import pipeline_ctl as pc
+    from test_oracle_golden import g15_case
+    t, meta, sd32, vsd, usd, tok, enc = g15_case(golden)
+    call, cfgp = dict(meta["call"]), meta["pipeline_config"]
+    pos, neg = t["prompt_embeds"], t["negative_prompt_embeds"]
+    truth = t["images"]
+    eager, _, _ = pc.multiscale_call(
+        sd32, meta["dit_cfg"], vsd, meta["vae_cfg"], usd, meta["upsampler_cfg"], pos, neg, t["prompt_attention_mask"],
+        t["negative_prompt_attention_mask"], call["height"], call["width"], call["num_frames"], call["frame_rate"],
+        cfgp["downscale_factor"], cfgp["first_pass"], cfgp["second_pass"], call["num_inference_steps1"],
+        call["num_inference_steps2"], t["noise.0"], t["noise.1"], t["decode_noise"], cfgp["decode_timestep"],
+        cfgp["decode_noise_scale"], dtype=BF, vae_dtype=BF, stats=vsd)
+
+    m = build_model(meta["dit_cfg"], sd32)
+    vae = build_vae(dict(meta["vae_cfg"], build_encoder=False), vsd)
+    ups = ltxmi.LatentUpsampler.from_config(meta["upsampler_cfg"])
+    ups.load_state_dict(usd)
+    ups = ups.to(device=DEV, dtype=BF).eval()
+    # the constructor call of ltxv.py:219-233, keyword for keyword
+    pipe = ltxmi.LTXVideoPipeline(
+        transformer=m, patchifier=ltxmi.SymmetricPatchifier(patch_size=1), text_encoder=enc.to(DEV), tokenizer=tok,
+        scheduler=ltxmi.RectifiedFlowScheduler(sampler="Uniform", shifting="SD3", base_resolution=None, target_shift_terminal=0.1),
+        vae=vae, prompt_enhancer_image_caption_model=None, prompt_enhancer_image_caption_processor=None,
+        prompt_enhancer_llm_model=None, prompt_enhancer_llm_tokenizer=None, allowed_inference_steps=None)
+    ms = ltxmi.LTXMultiScalePipeline(pipe, ups)
+    seen = {}
+    up = ms._upsample_latents
+
+    def spy(upsampler, latents):
+        out = up(upsampler, latents)
+        seen["pass1"], seen["upsampled"] = latents.float().cpu(), out.float().cpu()
+        return out
+
+    ms._upsample_latents = spy
+    trace = []
+
+    def callback(i, preview, start, **kw):
+        trace.append([int(i), None if preview is None else list(preview.shape), bool(start), int(kw.get("pass_no", 0)),
+                      kw.get("override_num_inference_steps")])
+
+    draws = [t["noise.0"], t["noise.1"]]
+    plain_randn = torch.randn
+
+    def recorded_randn(shape, *a, generator=None, device=None, dtype=None, **k):
+        n = draws.pop(0)
+        assert tuple(shape) == tuple(n.shape)
+        return n.to(device=device, dtype=dtype)
+
+    call["device"] = DEV                                      # (the reference ran with device="cpu")
+    with mock.patch.object(torch, "randn", recorded_randn), \
+            mock.patch.object(torch, "randn_like", lambda x, **k: t["decode_noise"].to(device=x.device, dtype=x.dtype)):
+        images = ms(**cfgp, ltxv_model=types.SimpleNamespace(_interrupt=False),
+                    skip_layer_strategy=ltxmi.SkipLayerStrategy[meta["skip_layer_strategy"]],
+                    generator=torch.Generator(device=DEV).manual_seed(155), callback=callback, **call)
+    assert torch.randn is plain_randn and not draws
+    assert trace == meta["callback_trace"]
+    assert images.shape == truth.shape == tuple(meta["images_shape"]) and images.dtype == BF
+    e1 = rel(seen["pass1"], t["pass1_latents"])
+    print(f"G15 replay: pass-1 latents rel L2 {e1:.3e}, upsampled {rel(seen['upsampled'], t['upsampled']):.3e}")
+    assert_parity(images, truth, eager, "ltxv.py's pipeline call through ltxmi.LTXMultiScalePipeline vs the reference's own run")
+    # an interrupt raised before the first pass comes back as None, as in the reference (:1854-1855)
+    call2 = dict(call)
+    assert ms(**cfgp, ltxv_model=types.SimpleNamespace(_interrupt=True), callback=None,
+              skip_layer_strategy=ltxmi.SkipLayerStrategy.AttentionValues, generator=None, **call2) is None
 
 
 def test_ulysses_processor_world1_matches_default_processor():
@@ -1058,10 +1206,75 @@ def test_ulysses_processor_world1_matches_default_processor():
         sp.enable_sequence_parallel(m)
         out = sp.usp_dit_forward(m, x.to(DEV), fc, **kw)[0]
         torch.cuda.synchronize()
+        # the identity short-cut off: dist.all_to_all_single (RCCL) really runs on the zero-copy send / receive buffers, the
+        # attention kernel reads the receive buffer through its strides, to_out takes the return buffer as a K-blocked
+        # operand -- on this one GPU, with a one-rank group (a copy by RCCL): still the default processor's bits
+        sp.enable_sequence_parallel(m, exchange_at_world_1=True)
+        assert all(b.attn1.processor.exchange_at_world_1 for b in m.transformer_blocks)
+        calls = []
+        a2a = dist.all_to_all_single
+
+        def counted(recv, send, **k):
+            calls.append((tuple(send.shape), send.is_cuda))
+            return a2a(recv, send, **k)
+
+        dist.all_to_all_single = counted
+        try:
+            forced = sp.usp_dit_forward(m, x.to(DEV), fc, **kw)[0]
+            torch.cuda.synchronize()
+        finally:
+            dist.all_to_all_single = a2a
+        assert len(calls) == 2 * len(m.transformer_blocks) and all(c[1] for c in calls)
+        # and as the pipeline sees it: model.forward rebound (the reference's MethodType pattern)
+        sp.enable_sequence_parallel(m, bind_forward=True, exchange_at_world_1=True)
+        bound = m(x.to(DEV), freqs_cis=fc, return_dict=False, **kw)[0]
+        torch.cuda.synchronize()
+        sp.disable_sequence_parallel(m)
+        again = m(x.to(DEV), freqs_cis=fc, return_dict=False, **kw)[0]
     finally:
         if created:
             dist.destroy_process_group()
     assert torch.equal(out, ref)
+    assert torch.equal(forced, ref)
+    assert torch.equal(bound, ref) and torch.equal(again, ref)
+
+
+def test_microbatched_block_loop_as_the_first_forward_of_a_fresh_model():
+    """the micro-batched block loop (two row slices, a side stream each -- the overlap mode of sequence
+    parallelism, reachable at world size 1 through ``_microbatches``) as the VERY FIRST forward of a fresh model: the packed
+    projection weights are built on the main stream before the side streams fork, so slice 1 can never read a pack that
+    stream 0 is still writing.  Compared bit for bit with a second fresh model run without micro-batches; again after the
+    packs were invalidated; again with step-invariant caching off (the stacked text K/V then serve every slice); and with
+    ``stg_alias_blocks`` (which takes the plain loop)."""
+    import ltxmi
+    grid, B, T = (2, 4, 8), 3, 24
+    cfg, sd32, x, enc, mask, ts, frac = dit_case(2, 64, 3, grid, B, T, seed=12)
+    x[2], enc[2], mask[2], ts[2] = x[1], enc[1], mask[1], ts[1]            # the STG row repeats the text row's inputs
+    slices = [slice(0, 1), slice(1, 3)]
+
+    def run(model, **extra):
+        fc = model.precompute_freqs_cis(frac.to(DEV))
+        out = model(x.to(DEV).clone(), freqs_cis=fc, encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV),
+                    timestep=ts.to(DEV), latent_shape=grid, ltxv_model=_Holder(), return_dict=False, **extra)[0]
+        torch.cuda.synchronize()
+        return out
+
+    fresh = build_model(cfg, sd32)
+    assert all(not b.attn1._packs and not b.attn2._packs for b in fresh.transformer_blocks)
+    first = run(fresh, _microbatches=slices)                               # nothing was ever packed before this call
+    plain = run(build_model(cfg, sd32))
+    assert torch.equal(first, plain)
+    for b in fresh.transformer_blocks:
+        b.attn1.invalidate_packed()
+        b.attn2.invalidate_packed()
+    assert torch.equal(run(fresh, _microbatches=slices), plain)
+    ltxmi.set_step_invariant_caching(False)
+    try:
+        assert torch.equal(run(build_model(cfg, sd32), _microbatches=slices), plain)
+        assert torch.equal(run(fresh, _microbatches=slices, stg_alias_blocks=2), plain)
+    finally:
+        ltxmi.set_step_invariant_caching(True)
+    assert torch.equal(run(fresh, _microbatches=slices, stg_alias_blocks=2), plain)
 
 
 # ------------------------------------------------------------------------------- Ulysses at world size 2, real kernels

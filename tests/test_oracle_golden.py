@@ -424,3 +424,65 @@ def test_g6_scheduler_stochastic_step(golden):
     for name, tt in (("global", tsched[2][None, None].expand(1, 24)), ("per_token", t["step.tok_t"])):
         out = sched.scheduler_step(tsched, t["step.v"], tt, t["step.sample"], stochastic_noise=t[f"step.stochastic_{name}_noise"])
         torch.testing.assert_close(out, t[f"step.stochastic_{name}"], **TOL)
+
+
+def test_g0_timestep_embedding(golden):
+    """G0: oracle/leaves.py::get_timestep_embedding against the reference's own in-repo copy
+    (ltx_video/models/transformers/embeddings.py:10-50) -- the one diffusers-shaped leaf that IS pinned."""
+    from oracle import leaves
+    t, _ = golden("g0_timestep_embedding")
+    ts = t["timesteps"]
+    assert torch.equal(leaves.get_timestep_embedding(ts, 256, flip_sin_to_cos=True, downscale_freq_shift=0.0),
+                       t["emb_256_flip_shift0"])
+    assert torch.equal(leaves.get_timestep_embedding(ts, 64), t["emb_64_defaults"])
+    assert torch.equal(leaves.get_timestep_embedding(ts, 33, False, 1, 2.0, 1000), t["emb_33_odd_scale2"])
+
+
+def g15_case(golden):
+    """Everything the G15 replay needs, rebuilt from the manifest: the DiT weights are G7's, the VAE decoder and the latent
+    upsampler come from the oracle's seeded initialisers (fingerprints checked, so an RNG drift fails loudly here and not
+    as a parity miss), the prompts go through the same fake T5 as in the generator."""
+    from oracle import upsampler as ou, vae as ov
+    from fake_t5 import FakeTextEncoder, FakeTokenizer
+    t, meta = golden("g15_multiscale_call")
+    w, _ = golden("g7_pipeline_call")
+    sd = sub(w, "w.")
+    vsd = ov.init_state_dict(meta["vae_cfg"], seed=meta["vae_seed"])
+    usd = ou.init_state_dict(meta["upsampler_cfg"], seed=meta["upsampler_seed"])
+
+    def fingerprint(d):
+        return float(sum(v.double().abs().sum() for v in d.values()))
+
+    assert abs(fingerprint(vsd) - meta["vae_fingerprint"]) < 1e-6 * meta["vae_fingerprint"], "seeded VAE weights drifted"
+    assert abs(fingerprint(usd) - meta["upsampler_fingerprint"]) < 1e-6 * meta["upsampler_fingerprint"]
+    tok, enc = FakeTokenizer(), FakeTextEncoder(meta["dit_cfg"]["caption_channels"], seed=meta["text_encoder_seed"]).eval()
+    return t, meta, sd, vsd, usd, tok, enc
+
+
+def test_g15_multiscale_call_with_ltxv_kwargs(golden):
+    """G15: the reference's own LTXMultiScalePipeline.__call__ run with the keyword arguments of ltxv.py:420-445 (YAML spread,
+    string prompts, output_type "pt", callback).  (1) the fake T5 + the reference's encode_prompt arithmetic reproduce the
+    recorded embeddings; (2) the oracle's two-pass restatement lands on the recorded pass-1 latents, upsampled latents and
+    final video."""
+    from oracle import pipeline_ctl as pc
+    t, meta, sd, vsd, usd, tok, enc = g15_case(golden)
+    call, cfgp = meta["call"], meta["pipeline_config"]
+    with torch.no_grad():
+        ti = tok([call["prompt"].strip()], padding="max_length", max_length=256, truncation=True)
+        pos = enc(ti.input_ids, attention_mask=ti.attention_mask)[0]
+        ni = tok([call["negative_prompt"].strip()], padding="max_length", max_length=256, truncation=True)
+        neg = enc(ni.input_ids, attention_mask=ni.attention_mask)[0]
+    assert torch.equal(pos, t["prompt_embeds"]) and torch.equal(neg, t["negative_prompt_embeds"])
+    assert torch.equal(ti.attention_mask.float(), t["prompt_attention_mask"])
+    assert torch.equal(ni.attention_mask.float(), t["negative_prompt_attention_mask"])
+    video, lat1, up = pc.multiscale_call(
+        sd, meta["dit_cfg"], vsd, meta["vae_cfg"], usd, meta["upsampler_cfg"], pos, neg, t["prompt_attention_mask"],
+        t["negative_prompt_attention_mask"], call["height"], call["width"], call["num_frames"], call["frame_rate"],
+        cfgp["downscale_factor"], cfgp["first_pass"], cfgp["second_pass"], call["num_inference_steps1"],
+        call["num_inference_steps2"], t["noise.0"], t["noise.1"], t["decode_noise"], cfgp["decode_timestep"],
+        cfgp["decode_noise_scale"], stats=vsd)
+    torch.testing.assert_close(lat1, t["pass1_latents"], rtol=5e-5, atol=1e-5)
+    torch.testing.assert_close(up, t["upsampled"], rtol=5e-5, atol=1e-5)
+    assert video.shape == t["images"].shape == tuple(meta["images_shape"])
+    assert float(t["images"].std()) > 0.02                       # a real picture, not the clamp's floor / ceiling
+    torch.testing.assert_close(video, t["images"], rtol=1e-4, atol=1e-4)
