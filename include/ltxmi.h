@@ -20,7 +20,7 @@
  *   - argument structs (ltxmi_*_args) MUST be zero-initialised before the fields in use are
  *     set (`ltxmi_gemm_args a = {0};` / memset): versions append optional fields at the tail
  *     (0.2: rowsumsq*, a_kblock* of ltxmi_gemm_args; q_rowsumsq*, q_norm*, rope_*, o_segment*
- *     of ltxmi_attn_args; 0.3: q_rstd*; 0.4: conv3d post_*), and a zero there means "off".  A caller must be
+ *     of ltxmi_attn_args; 0.3: q_rstd*; 0.4: conv3d post_*; 0.5: redo_counter, force_exact of ltxmi_attn_args), and a zero there means "off".  A caller must be
  *     rebuilt against the header of the library it loads.  An optional pointer that is NULL
  *     switches its companion size / stride fields off whatever they hold.
  */
@@ -173,6 +173,14 @@ typedef struct ltxmi_attn_args {
      * it replaces q_rowsumsq (every workgroup -- one per head and query tile -- then reads 4 bytes per row instead of
      * re-summing H*head_dim/64 partials); q_norm_weight / rope_* as above.  NULL = off. */
     const float* q_rstd; int64_t q_rstd_stride_b, q_rstd_stride_l;
+    /* 0.5 -- diagnostics of the pipelined kernels' normal run.  They take P = 2^s against the fixed reference 0 for every row
+     * (no running maximum), which is exact as long as a row's scaled scores stay within about +-100 bits (+-69 nats): a
+     * (batch, head, 256-query) item whose row sums or accumulators leave [2^-100, 2^100) is detected by its workgroup after the
+     * last key tile and run again with the textbook online softmax ("exact form"), so the RESULT never depends on the range --
+     * only the time does.  redo_counter: optional device word, incremented once per item that was redone (the caller zeroes
+     * it); force_exact != 0: every item takes the exact form at once (what a launch costs when nothing fits the range).
+     * Ignored by the register-staged kernel, which has the exact form only. */
+    uint32_t* redo_counter; int32_t force_exact;
 } ltxmi_attn_args;
 
 int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* args, void* stream);

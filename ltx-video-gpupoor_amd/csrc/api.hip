@@ -65,6 +65,6 @@ int device_cu_count(const char* what) {
 
 }  // namespace ltxmi
 
-extern "C" const char* ltxmi_version(void) { return "ltxmi 0.4.0 (round 3)"; }
+extern "C" const char* ltxmi_version(void) { return "ltxmi 0.5.0 (round 4)"; }
 extern "C" const char* ltxmi_last_error(void) { return ltxmi::g_err; }
 extern "C" const char* ltxmi_arch(void) { return "gfx950"; }

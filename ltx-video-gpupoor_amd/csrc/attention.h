@@ -23,6 +23,9 @@ struct AttnParams {
     // optional: the output's token axis is cut into segments of o_seg tokens, o_sseg elements apart (Ulysses: the
     // return all-to-all's send buffer [P dst][B][N / P][H dh]); 0 = one segment
     int o_seg; int64_t o_sseg;
+    // diagnostics of the pipelined kernels' steady (reference-0) form: a device counter that every workgroup whose item had to
+    // be redone in the exact form bumps once (nullptr = off), and a switch that sends EVERY item straight to the exact form
+    uint32_t* redo_count; int force_exact;
 
     __host__ __device__ __forceinline__ bool q_on_load() const { return q_ss != nullptr || q_rstd != nullptr; }
     // q's RMSNorm factor of row `row` of batch b (HD = H * head_dim, the normalised width)

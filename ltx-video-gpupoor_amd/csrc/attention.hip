@@ -483,6 +483,7 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     p.rope_cos = (const uint16_t*)a->rope_cos; p.rope_sin = (const uint16_t*)a->rope_sin;
     p.rope_sb = a->rope_stride_b; p.rope_sl = a->rope_stride_l;
     p.o_seg = a->o_segment_len; p.o_sseg = a->o_stride_segment;
+    p.redo_count = a->redo_counter; p.force_exact = a->force_exact != 0;
     LTXMI_REQUIRE(a->o_segment_len >= 0 && a->o_stride_segment % 8 == 0, LTXMI_ERR_INVALID_ARG,
                   "ltxmi_attention_fwd_bf16: bad output segment geometry");
     const bool span_ok = attn_pipe_span_ok(a->Lk, a->k_stride_l, a->v_stride_l, a->head_dim);

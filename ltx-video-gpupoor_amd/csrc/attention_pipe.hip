@@ -187,9 +187,11 @@ __device__ __forceinline__ void segment(Blk& X, Blk& Y, bf16x8 (&kf)[8], const c
     STAMP(st0 + 1);
 }
 
-// One work item = one (batch, head, 256-row query tile).  REDO = false: the normal run (exact form for the first two key
-// tiles, steady form for the rest, then the check for outgrown references); returns true -- WITHOUT having stored anything --
-// when the workgroup has to go through the item again.  REDO = true: exact form throughout, always stores.
+// One work item = one (batch, head, 256-row query tile).  REDO = false: the normal run -- EVERY key tile in the steady form
+// (P = 2^s against the fixed reference 0: no tile maximum, no running maximum, no rescale; t_exact = 0 below), then the
+// range check on row sums and accumulators: a row whose scores left about +-100 bits (69 nats) has a sum or accumulator
+// outside [2^-100, 2^100) -- the item then returns true WITHOUT having stored anything and the workgroup goes through it
+// again.  REDO = true: the exact (textbook online-softmax) form for every key tile, always stores.
 // QSCALED = q is produced on load (the fused K1 below): softmax_scale * log2(e) goes into it before its one rounding to bf16
 // and the scores leave the matrix pipe in bits.  A q that arrives as bf16 is left as it is (scaling it would round it a second
 // time, an error proportional to the score: visible once logits reach tens of nats) and its scores take one v_mul each.
@@ -534,7 +536,10 @@ template <int OCC, bool QSCALED>
 __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    if (!attn_pipe_item<false, QSCALED>(p, tid, smem)) return;
+    if (!p.force_exact) {                                                  // (a kernel argument: scalar, wave-uniform)
+        if (!attn_pipe_item<false, QSCALED>(p, tid, smem)) return;
+        if (p.redo_count != nullptr && tid == 0) atomicAdd(p.redo_count, 1u);
+    }
     // (rare) the item again, exact form throughout.  The thread id is laundered through an empty asm so that nothing the first
     // run derived from it is kept alive -- i.e. spilled -- across its loops for this path's sake: everything is recomputed.
     int tid2 = tid;
@@ -558,10 +563,7 @@ extern "C" int ltxmi_debug_set_attn_stamps(void* buf) {
 bool attn_pipe_takes(int B, int H, int Lq, int Lk, int head_dim, bool has_bias) {
     // from 192 workgroups of 256 rows (of the chip's 512 slots) this kernel beats attention.hip's: measured +11 % at 240
     // and +20 % at 480 workgroups (B 3, N 4992 with 4 / 8 heads: what a rank sees in the Ulysses mode at P = 8 / 4)
-#ifndef LTXMI_PIPE_MIN_WGS
-#define LTXMI_PIPE_MIN_WGS 192
-#endif
-    return head_dim == 64 && !has_bias && (int64_t)B * H * ((Lq + 255) / 256) >= LTXMI_PIPE_MIN_WGS && Lk > 0;
+    return head_dim == 64 && !has_bias && (int64_t)B * H * ((Lq + 255) / 256) >= 192 && Lk > 0;
 }
 
 int launch_attn_pipe(AttnParams p, hipStream_t stream) {

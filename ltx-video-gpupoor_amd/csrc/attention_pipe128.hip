@@ -350,7 +350,8 @@ __global__ __launch_bounds__(256, 1) void attn_pipe128_kernel(AttnParams p) {
     if (tid == 0) *redo_flag = 0;
     // attempt 0: exact form for the first two key tiles, steady form for the rest; attempt 1 (only if some wave of the
     // workgroup saw a score outgrow its reference): the whole item again in the exact form
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = p.force_exact ? 1 : 0; attempt < 2; ++attempt) {
+        if (attempt == 1 && !p.force_exact && p.redo_count != nullptr && tid == 0) atomicAdd(p.redo_count, 1u);
         dma_k(0); dma_v(0); dma_k(1); dma_v(1); dma_k(2);
         init(A, 0);
         init(Bk, 1);
@@ -494,13 +495,7 @@ __global__ __launch_bounds__(256, 1) void attn_pipe128_kernel(AttnParams p) {
 bool attn_pipe128_takes(int B, int H, int Lq, int Lk, int head_dim, bool has_bias) {
     // one 256-row workgroup per CU: from about half a chip's worth of workgroups on, and with enough key tiles for the
     // ring's prologue / drain to amortise (the 512-key text cross-attention of config 4 stays on the register-staged kernel)
-#ifndef LTXMI_PIPE128_MIN_WGS
-#define LTXMI_PIPE128_MIN_WGS 128
-#endif
-#ifndef LTXMI_PIPE128_MIN_KEYS
-#define LTXMI_PIPE128_MIN_KEYS 1024
-#endif
-    return head_dim == 128 && !has_bias && (int64_t)B * H * ((Lq + 255) / 256) >= LTXMI_PIPE128_MIN_WGS && Lk >= LTXMI_PIPE128_MIN_KEYS;
+    return head_dim == 128 && !has_bias && (int64_t)B * H * ((Lq + 255) / 256) >= 128 && Lk >= 1024;
 }
 
 int launch_attn_pipe128(AttnParams p, hipStream_t stream) {

@@ -829,9 +829,6 @@ extern "C" int ltxmi_debug_set_conv_stamps(void* buf) {
 #endif
 namespace ltxmi {
 
-#ifndef LTXMI_CD_V3
-#define LTXMI_CD_V3 1
-#endif
 // the shapes the direct convolution takes at all (either form)
 static bool conv3d_direct_takes(const ltxmi_conv3d_args* a) {
     const int st = a->stride_t > 0 ? a->stride_t : 1, sh = a->stride_hw > 0 ? a->stride_hw : 1;
@@ -848,7 +845,7 @@ static int64_t conv3d_direct_grid(const ltxmi_conv3d_args* a) {
 // whole 128-channel blocks: the four-wave form, two workgroups per CU (algo 3 asks for it, algo 4 for the eight-wave form)
 // (from 768 workgroups = 1.5 rounds of the chip's 512 slots; measured: 896 workgroups +5.8 %, 600 -0.6 %, 224 -21 %)
 static bool conv3d_direct_four_wave_form(const ltxmi_conv3d_args* a, int64_t grid) {
-    return a->Cout % 128 == 0 && grid < (1ll << 31) && ((LTXMI_CD_V3 && a->algo != 4 && grid >= 768) || a->algo == 3);
+    return a->Cout % 128 == 0 && grid < (1ll << 31) && ((a->algo != 4 && grid >= 768) || a->algo == 3);
 }
 // ltxmi_conv3d_fuses_post_norm: the four-wave form with ONE 128-channel block (a wave then holds every channel of its positions)
 bool conv3d_direct_fuses_post_norm(const ltxmi_conv3d_args* a) {

@@ -660,11 +660,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_nt_persistent
     unsigned long long gst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gst_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gst_prev)::"memory");
 #endif
-#if defined(LTXMI_GEMM_PRIO) && LTXMI_GEMM_PRIO == 1
-    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);      // experiment: the younger half of the workgroup
-#elif defined(LTXMI_GEMM_PRIO) && LTXMI_GEMM_PRIO == 2
-    if (wave < NW / 2) __builtin_amdgcn_s_setprio(1);       // experiment: the LDS-DMA issuing half
-#endif
     const int nk = p.K / BK;                 // >= 2 on this path
     int cs_m0, cs_n0, ns_m0 = 0, ns_n0 = 0;
     tile_origin(0, cs_m0, cs_n0);

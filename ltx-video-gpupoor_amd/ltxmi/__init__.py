@@ -9,9 +9,9 @@ from .attention import (Attention, AttnProcessor2_0, BasicTransformerBlock, Feed
                         SkipLayerStrategy)
 from .attention_seam import pay_attention  # noqa: F401
 from .autoencoder import (CausalVideoAutoencoder, DecoderOutput, AutoencoderKLOutput,  # noqa: F401
-                          DiagonalGaussianDistribution, vae_decode, vae_encode)
+                          DiagonalGaussianDistribution, normalize_latents, un_normalize_latents, vae_decode, vae_encode)
 from .patchifier import SymmetricPatchifier, latent_to_pixel_coords_from_factors  # noqa: F401
-from .pipeline import ConditioningItem, LTXMultiScalePipeline, LTXVideoPipeline  # noqa: F401
+from .pipeline import ConditioningItem, LTXMultiScalePipeline, LTXVideoPipeline, retrieve_timesteps  # noqa: F401
 from .latent_upsampler import LatentUpsampler, adain_filter_latent, upsample_latents  # noqa: F401
 from .scheduler import RectifiedFlowScheduler  # noqa: F401
 from .transformer3d import Transformer3DModel, Transformer3DModelOutput  # noqa: F401

@@ -40,7 +40,8 @@ class AttnArgs(ctypes.Structure):
                 ("q_rowsumsq_blocks", c_int), ("q_norm_weight", c_void_p), ("q_norm_eps", c_float),
                 ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("rope_stride_b", c_int64), ("rope_stride_l", c_int64),
                 ("o_segment_len", c_int), ("o_stride_segment", c_int64),
-                ("q_rstd", c_void_p), ("q_rstd_stride_b", c_int64), ("q_rstd_stride_l", c_int64)]
+                ("q_rstd", c_void_p), ("q_rstd_stride_b", c_int64), ("q_rstd_stride_l", c_int64),
+                ("redo_counter", c_void_p), ("force_exact", c_int)]
 
 
 class Conv3dArgs(ctypes.Structure):

@@ -204,14 +204,17 @@ def attention_kernel_id(B, H, Lq, Lk, dh, has_key_bias=False, k_stride_l=None, v
     return int(lib.ltxmi_attention_kernel_id(B, H, Lq, Lk, dh, int(has_key_bias), ks, vs))
 
 
-def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None, rope=None, out_segments=None):
+def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None, rope=None, out_segments=None,
+              redo_counter=None, force_exact=False):
     """q [B,Lq,H,dh], k/v [B,Lk,H,dh] (NHD; batch and token strides free, (H,dh) contiguous).
     key_bias: fp32 [B,Lk] additive (broadcast over heads and queries).
     q_norm = (rowsumsq fp32 [B*Lq, H*dh/64] from ``gemm(..., rowsumsq=)`` OR the finalised factor fp32 [B*Lq] from
     ``rmsnorm_rope_(..., rstd_of=)``, weight bf16 [H*dh], eps): q is the raw projection output and is RMS-normalised over
     all heads (+ rotated with rope = (cos [period, H*dh], sin, period)) while the kernel loads it.
     out_segments = (tokens per segment, elements between segments): ``out`` is segment 0's [B, segment, H, dh] view of a
-    buffer whose token axis is cut into such segments (the Ulysses return all-to-all's send buffer)."""
+    buffer whose token axis is cut into such segments (the Ulysses return all-to-all's send buffer).
+    redo_counter (diagnostic): int32 device tensor of one element, incremented once per (batch, head, query tile) item the
+    pipelined kernels had to run again in the exact online-softmax form; force_exact: every item in that form."""
     _chk_bf16(q, k, v, out)
     B, Lq, H, dh = q.shape
     Lk = k.shape[1]
@@ -267,6 +270,11 @@ def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None,
             a.rope_stride_b = 0 if period == Lq else Lq * cos.stride(0)
     elif rope is not None:
         raise ValueError("ltxmi.attention: rope needs q_norm")
+    if redo_counter is not None:
+        if redo_counter.dtype != torch.int32 or redo_counter.numel() != 1 or not redo_counter.is_cuda:
+            raise ValueError("ltxmi.attention: redo_counter must be a CUDA int32 tensor of one element")
+        a.redo_counter = redo_counter.data_ptr()
+    a.force_exact = int(bool(force_exact))
     tok = _prof_begin(("attention", B, H, Lq, Lk, dh))
     check(lib.ltxmi_attention_fwd_bf16(ctypes.byref(a), _stream()), "ltxmi_attention_fwd_bf16")
     _prof_end(tok)

@@ -237,6 +237,76 @@ def test_attention_pipelined_kernel_head_dim_128(Lq, Lk, spike):
     check(out, attn_truth(q, k, v), what=f"head_dim-128 pipelined attention Lq{Lq} Lk{Lk} spike={spike}")
 
 
+def _time_ms(fn, iters=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def test_attention_trained_like_logits_and_the_redo_counter():
+    """the steady (reference-0) form is only ever TIMED on random-init logits of a few nats.  Here, at the
+    workload's shape (B 3, H 32, N 4992, head_dim 64): (1) trained-like logits -- row maxima of 30-50 nats, softmax nearly
+    one-hot -- must need NO redo (device counter) and sit inside the oracle band; (2) with a score of ~+85 nats planted in
+    10 % of the (batch, head, query tile) items exactly those items are redone (counter), the result stays inside the band,
+    and the time is printed next to the all-steady and the all-exact (``force_exact``) launches."""
+    from ltxmi import ops
+    B, H, N, dh = 3, 32, 4992, 64
+    assert ops.attention_kernel_id(B, H, N, N, dh, False, H * dh, H * dh) == 3
+    # "trained-like": every query has ONE key it is aligned with (its own token's: the diagonal of self-attention) at ~+40 nats,
+    # all other pairs are noise of ~6 nats -- a softmax that is nearly one-hot, with its maximum anywhere in the key sequence.
+    # (Plain N(0, sigma^2) q / k with the same typical maxima do not work as a NO-redo case: q.k is a sum of products of
+    # normals, its far tail is much heavier than a Gaussian's, and among 2.4e9 scores one lands beyond +69 nats -- measured.)
+    q, v = rnd(B, N, H, dh, seed=60, scale=2.0), rnd(B, N, H, dh, seed=62)
+    qf = q.float()
+    k = (rnd(B, N, H, dh, seed=61, scale=2.0).float() + qf * (40.0 * 8.0 / (qf * qf).sum(-1, keepdim=True))).to(BF)
+    rows = torch.cat([torch.arange(0, 64), torch.arange(2500, 2564), torch.arange(N - 64, N)])      # a band of query rows
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+
+    def band_truth(qq, kk):
+        return attn_truth(qq[:, rows], kk, v)
+
+    s = torch.einsum("bqhd,bkhd->bhqk", q[:1, rows].float(), k[:1].float()) / 8.0
+    mx = s.amax(dim=-1)
+    print(f"trained-like logits: row maxima {float(mx.min()):.1f} .. {float(mx.max()):.1f} nats (median {float(mx.median()):.1f})")
+    assert 30.0 < float(mx.median()) < 50.0 and float(mx.max()) < 66.0
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = ops.attention(qd, kd, vd, redo_counter=counter)
+    assert int(counter.item()) == 0                                  # inside the steady form's range: nothing is redone
+    check(out[:, rows], band_truth(q, k), what="trained-like logits, steady form")
+    exact = ops.attention(qd, kd, vd, force_exact=True)
+    check(exact[:, rows], band_truth(q, k), what="trained-like logits, exact form forced")
+    t_steady = _time_ms(lambda: ops.attention(qd, kd, vd))
+    t_exact = _time_ms(lambda: ops.attention(qd, kd, vd, force_exact=True))
+
+    # ~10 % of the items beyond the range: per (batch, head) two query tiles get one row aligned with one key
+    k2 = k.clone()
+    tiles = (3, 11)                                                   # query tiles of 256 rows (of 20)
+    for j, t in enumerate(tiles):
+        row, key = 256 * t + 17 + 64 * j, 1000 + 2000 * j
+        qrow = q[:, row].float()                                     # [B, H, dh]
+        k2[:, key] = (qrow * (85.0 * 8.0 / (qrow * qrow).sum(-1, keepdim=True))).to(BF)       # score ~ +85 nats = 123 bits
+    rows2 = torch.cat([rows, torch.tensor([256 * 3 + 17, 256 * 11 + 17 + 64, 256 * 3 + 100])])
+    counter.zero_()
+    k2d = k2.to(DEV)
+    out2 = ops.attention(qd, k2d, vd, redo_counter=counter)
+    n_items = B * H * ((N + 255) // 256)
+    assert int(counter.item()) == len(tiles) * B * H, (int(counter.item()), n_items)
+    check(out2[:, rows2], attn_truth(q[:, rows2], k2, v), what="10 % of the items redone")
+    t_redo = _time_ms(lambda: ops.attention(qd, k2d, vd))
+    qr, kr = rnd(B, N, H, dh, seed=63).to(DEV), rnd(B, N, H, dh, seed=64).to(DEV)
+    t_rand = _time_ms(lambda: ops.attention(qr, kr, vd))
+    print(f"attention B{B} H{H} N{N}: N(0,1) q / k (what random-init weights give) {t_rand:.3f} ms;  trained-like logits: all steady "
+          f"{t_steady:.3f} ms, {len(tiles) * B * H}/{n_items} items redone {t_redo:.3f} ms, exact form forced {t_exact:.3f} ms")
+    # (times are reported, not asserted, beyond their order: a redone item runs twice, the second time in the slower form)
+    assert t_steady < t_redo < t_exact * 1.5
+
+
 def test_pay_attention_seam_contract():
     from ltxmi import pay_attention
     B, L, H, dh = 2, 130, 2, 64
@@ -318,6 +388,21 @@ def test_small_pointwise():
     d = a.to(DEV).clone()
     ops.stg_blend_(d, v.to(DEV), m.to(DEV))
     check(d, a.float() * m[:, None, None] + v.float() * (1 - m[:, None, None]), what="stg blend")
+
+
+def test_timestep_embedding_kernel_against_the_references_own_sinusoid(golden):
+    """G0: ``ltxmi_timestep_embedding_bf16`` against the reference's own ``get_timestep_embedding``
+    (ltx_video/models/transformers/embeddings.py:10-50; golden generated by importing it untouched) on scaled, fractional,
+    zero and per-frame timestep values -- bf16 outputs of values in [-1, 1]: one rounding (<= 2^-9) plus the kernel's fp32
+    argument reduction at arguments up to 1000 rad."""
+    from ltxmi import ops
+    t, _ = golden("g0_timestep_embedding")
+    emb = ops.timestep_embedding(t["timesteps"].to(DEV), 256)
+    want = t["emb_256_flip_shift0"]
+    assert emb.shape == want.shape and emb.dtype == BF
+    err = (emb.float().cpu() - want).abs().max()
+    assert float(err) <= 2.0 ** -8, float(err)
+    check(emb, want, rel_l2=3e-3, what="sinusoid vs the reference's own")
 
 
 # ------------------------------------------------------------------------------ VAE
