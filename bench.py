@@ -268,6 +268,51 @@ def attention_band_check(q, k, v, out, what, rows=64):
         assert err < 2e-2, f"{what}: rows {r0}..{r0 + rows} differ from fp32 attention by {err:.3e}"
 
 
+def time_attention_forms(device, iters=20):
+    """The self-attention launch of the workload (B 3, H 32, N 4992, head_dim 64) in the kernel's two forms, and on two kinds of
+    logits: N(0,1) q / k (what random-init weights produce: a few nats) and "trained-like" ones (every query aligned with its
+    own token's key at ~+40 nats, everything else noise of ~6 nats: a nearly one-hot softmax).  steady = the normal run
+    (reference-0 softmax, range-checked); exact = every item forced through the textbook online softmax (``force_exact``) --
+    what the launch would cost if NOTHING fitted the +-100-bit range; redo_items = items the normal run had to redo."""
+    from ltxmi import ops
+    B, N = NUM_CONDS, N_TOK
+    g = torch.Generator(device=device).manual_seed(7)
+
+    def rnd(scale):
+        return (torch.randn(B, N, H, DH, generator=g, device=device, dtype=torch.float32) * scale).to(torch.bfloat16)
+
+    def ms(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    out = {"shape": [B, N, H, DH], "items": B * H * ((N + 255) // 256)}
+    flop = 4.0 * B * H * N * N * DH
+    q, k, v = rnd(1.0), rnd(1.0), rnd(1.0)
+    q2 = rnd(2.0)
+    qf = q2.float()
+    k2 = (rnd(2.0).float() + qf * (40.0 * 8.0 / (qf * qf).sum(-1, keepdim=True))).to(torch.bfloat16)
+    for name, (qq, kk) in (("random_logits", (q, k)), ("trained_like_logits", (q2, k2))):
+        cnt = torch.zeros(1, dtype=torch.int32, device=device)
+        o = ops.attention(qq, kk, v, redo_counter=cnt)
+        oe = ops.attention(qq, kk, v, force_exact=True)
+        assert torch.isfinite(o.float()).all() and torch.isfinite(oe.float()).all()
+        d = float((o.float() - oe.float()).norm() / oe.float().norm())
+        assert d < 6e-3, (name, d)                               # two bf16 renderings of the same softmax
+        t_s, t_e = ms(lambda: ops.attention(qq, kk, v)), ms(lambda: ops.attention(qq, kk, v, force_exact=True))
+        out[name] = {"steady_form_ms": round(t_s, 4), "exact_form_ms": round(t_e, 4), "redo_items": int(cnt.item()),
+                     "steady_frac_of_mfma_peak": round(flop / (t_s * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "exact_frac_of_mfma_peak": round(flop / (t_e * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "steady_vs_exact_rel_l2": round(d, 5)}
+    return out
+
+
 def time_attention(device, n_tok, iters, B=1, heads=H, dh=DH, lk=None):
     from ltxmi import ops
     g = torch.Generator(device=device).manual_seed(3)
@@ -771,16 +816,19 @@ def main():
         key_attn = ("attention", NUM_CONDS, H // sp, runner.n_tok, runner.n_tok, DH)
         for _ in range(args.warmup):
             runner.step()
+        redo = torch.zeros(1, dtype=torch.int32, device=device)
+        ops.count_attention_redos(redo)          # items of the self- / cross-attention launches redone in the exact form
         ops.watch_launches([key_ff1, key_attn])
         elapsed, per_step = timed_steps(runner.step, args.steps, dist)
         times = ops.launch_times_ms()
         ops.watch_launches(None)
+        ops.count_attention_redos(None)
         elapsed = max_over_ranks(elapsed, dist, device)
         assert torch.isfinite(runner.latents).all(), "non-finite latents after the timed steps"
         ff1, at = times.get(key_ff1, []), times.get(key_attn, [])
         ff1_ms, at_ms = sum(ff1) / max(len(ff1), 1), sum(at) / max(len(at), 1)
         return {"elapsed": elapsed, "per_step": per_step, "sp": sp, "M": M, "ff1_ms": ff1_ms, "n_ff1": len(ff1),
-                "at_ms": at_ms, "n_at": len(at)}
+                "at_ms": at_ms, "n_at": len(at), "redo_items": int(redo.item())}
 
     uly = uly3 = None
     if ulysses_only:
@@ -858,6 +906,13 @@ def main():
                          "hbm_gb_per_s": (round(traffic["attention_hbm_bytes_per_launch"] / (r["at_ms"] * 1e-3) / 1e9, 1)
                                           if traffic.get("attention_hbm_bytes_per_launch") and r["at_ms"] > 0 else None),
                          "launch_ms": round(r["at_ms"], 4), "launches_timed": r["n_at"],
+                         # the kernel's normal run is the reference-0 ("steady") softmax form, valid while scaled scores stay
+                         # within ~+-100 bits; items that leave the range are detected and redone in the exact form
+                         "redo_items": r["redo_items"],
+                         "items_per_launch": NUM_CONDS * (H // sp) * ((N_TOK + 255) // 256),
+                         "redo_note": "items (batch, head, 256-query tile) of ALL attention launches of the timed steps that "
+                                      "were redone in the exact online-softmax form (device counter); random-init weights give "
+                                      "logits of a few nats -- see attention.workload_exact_form for what the exact form costs",
                          "algorithmic_flop_per_launch": at_flop,
                          "algorithmic_bytes_per_launch": 8 * NUM_CONDS * N_TOK * (D // sp)},
             "roofline_gemm": {"kernel": f"gemm_bf16_nt_persistent_kernel<256,256,2,4,GELU_TANH> (ff.net.0, M={M} N=8192 K=2048)",
@@ -927,6 +982,7 @@ def main():
         del runner
         torch.cuda.empty_cache()
         line["attention"] = {
+            "workload_exact_form": time_attention_forms(device),
             "stress_98304": time_attention(device, 98304, 3),
             "config3_tokens_13376": time_attention(device, 13376, 20),
             "config4_wan_self_32760x12x128": time_attention(device, 32760, 20, heads=12, dh=128),

@@ -36,6 +36,17 @@ def watch_launches(keys):
     _events.clear()
 
 
+_redo_counter = None
+
+
+def count_attention_redos(counter):
+    """Diagnostic: an int32 CUDA tensor of one element that EVERY attention launch from now on bumps once per (batch, head,
+    query tile) item it had to redo in the exact form (``ops.attention(redo_counter=)``); None switches it off.  bench.py
+    keeps it on through the timed steps: the count is part of the bench line."""
+    global _redo_counter
+    _redo_counter = counter
+
+
 def launch_times_ms():
     """{key: [ms, ...]} for the watched launches (call after a stream/device synchronize)."""
     return {k: [a.elapsed_time(b) for a, b in v] for k, v in _events.items()}
@@ -270,6 +281,8 @@ def attention(q, k, v, out=None, key_bias=None, softmax_scale=None, q_norm=None,
             a.rope_stride_b = 0 if period == Lq else Lq * cos.stride(0)
     elif rope is not None:
         raise ValueError("ltxmi.attention: rope needs q_norm")
+    if redo_counter is None:
+        redo_counter = _redo_counter
     if redo_counter is not None:
         if redo_counter.dtype != torch.int32 or redo_counter.numel() != 1 or not redo_counter.is_cuda:
             raise ValueError("ltxmi.attention: redo_counter must be a CUDA int32 tensor of one element")
