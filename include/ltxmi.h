@@ -144,8 +144,10 @@ int ltxmi_rmsnorm_rope_rstd_bf16(void* x, int64_t ldx, int32_t rows, int32_t D, 
  * key_bias: optional fp32 [B, Lk] added to the scaled scores (broadcast over heads and queries).
  * head_dim in {64, 128}; Lq, Lk >= 1 (ragged tails are masked inside the kernel).
  * Kernels behind the entry point (chosen by shape, ltxmi_attention_kernel_id): the software-pipelined LDS-DMA kernels for
- * large bias-free shapes (head_dim 64: two waves per SIMD; head_dim 128: one wave per SIMD with the whole register file)
- * and the register-staged kernel for everything else (key bias, small shapes).
+ * large bias-free shapes (head_dim 64: two waves per SIMD; head_dim 128: one wave per SIMD with the whole register file),
+ * the short-key-sequence kernel (0.5: head_dim 64, <= 256 keys, >= 1024 queries -- the T5 cross-attention: K / V of a
+ * (batch, head) resident in LDS, a query row's scores all in registers, single-pass softmax; id 7)
+ * and the register-staged kernel for everything else (key bias with longer key sequences, small shapes).
  * ------------------------------------------------------------------------------- */
 typedef struct ltxmi_attn_args {
     const void* q; int64_t q_stride_b, q_stride_l;

@@ -61,6 +61,9 @@ bool attn_pipe_takes(int B, int H, int Lq, int Lk, int head_dim, bool has_bias);
 // attention_pipe128.hip: the same for head_dim 128 (one 4-wave workgroup per CU, 512 registers per wave)
 int launch_attn_pipe128(AttnParams p, hipStream_t stream);
 bool attn_pipe128_takes(int B, int H, int Lq, int Lk, int head_dim, bool has_bias);
+// attention_cross.hip: short key sequences (<= 256 keys, head_dim 64; the T5 cross-attention): K / V resident in LDS
+int launch_attn_cross(AttnParams p, hipStream_t stream);
+bool attn_cross_takes(int B, int H, int Lq, int Lk, int head_dim);
 // both pipelined kernels address a (batch, head)'s K / V rows through buffer descriptors with 32-bit byte offsets: the rows
 // of all key tiles (+ the ring's run-ahead) must span less than 2 GiB
 inline bool attn_pipe_span_ok(int Lk, int64_t k_sl, int64_t v_sl, int head_dim) {

@@ -142,6 +142,59 @@ def test_attention_key_bias_cross(dh):
     check(out, attn_truth(q, k, v, bias), what="cross")
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,bias", [(3, 32, 4992, 256, True),       # the DiT's cross-attention (5 row groups per (batch, head))
+                                            (2, 8, 1500, 200, True),        # ragged last key tile, ragged last iteration
+                                            (1, 5, 1024, 1, False), (2, 3, 2049, 64, False), (1, 4, 1100, 130, True),
+                                            (1, 40, 9000, 256, False)])     # more (batch, head) pairs than fit at once
+def test_attention_short_key_sequences_kernel(B, H, Lq, Lk, bias):
+    """attention_cross.hip (kernel id 7): head_dim 64, <= 256 keys resident in LDS, every query row's scores in registers at
+    once, single-pass softmax.  Against the fp32 oracle on the same bf16 inputs: hard (-10000) and soft key biases, key
+    counts that are not multiples of 64 (keys past Lk must not contribute), row counts that are not multiples of 128, k / v as
+    strided halves of one [B, Lk, 2, H, dh] projection buffer (how the DiT hands them over), a segmented output, q finished
+    on load (RMSNorm factor per row + weight) against the two-pass form."""
+    from ltxmi import ops
+    dh = 64
+    assert ops.attention_kernel_id(B, H, Lq, Lk, dh, bias, 2 * H * dh, 2 * H * dh) == 7
+    q = rnd(B, Lq, H, dh, seed=70)
+    kv = rnd(B, Lk, 2, H, dh, seed=71)
+    k, v = kv[:, :, 0], kv[:, :, 1]
+    kb = None
+    if bias:
+        kb = torch.zeros(B, Lk)
+        kb[0, Lk - Lk // 3:] = -10000.0                                     # the padded tail of a prompt
+        if B > 1:
+            kb[1] = torch.randn(Lk, generator=torch.Generator().manual_seed(2))        # a soft bias
+    kvd = kv.to(DEV)
+    out = ops.attention(q.to(DEV), kvd[:, :, 0], kvd[:, :, 1], key_bias=None if kb is None else kb.to(DEV))
+    rows = torch.cat([torch.arange(0, min(Lq, 160)), torch.arange(Lq - 140, Lq)]).unique()     # first rows, last (ragged) rows
+    truth = attn_truth(q[:, rows], k, v, kb)
+    check(out[:, rows], truth, what=f"short-key attention B{B} H{H} Lq{Lq} Lk{Lk}")
+    if Lq <= 2100:
+        check(out, attn_truth(q, k, v, kb), what=f"short-key attention, whole tensor, Lq{Lq} Lk{Lk}")
+    # segmented output (the Ulysses return exchange's send buffer): tokens in segments of Lq / 4
+    if Lq % 4 == 0:
+        seg = Lq // 4
+        buf = torch.zeros(4, B, seg, H, dh, dtype=BF, device=DEV)
+        ops.attention(q.to(DEV), kvd[:, :, 0], kvd[:, :, 1], key_bias=None if kb is None else kb.to(DEV), out=buf[0],
+                      out_segments=(seg, B * seg * H * dh))
+        assert torch.equal(buf.permute(1, 0, 2, 3, 4).reshape(B, Lq, H, dh), out)
+    # q finished on load: raw projection rows + one RMSNorm factor per row + weight
+    D = H * dh
+    g = torch.Generator(device=DEV).manual_seed(72)
+    qraw = (torch.randn(B * Lq, D, generator=g, device=DEV) * 1.7).to(BF)
+    wq = (1.0 + 0.1 * torch.randn(D, generator=g, device=DEV)).to(BF)
+    ss = qraw.float().reshape(B * Lq, D // 64, 64).pow(2).sum(-1).contiguous()
+    rstd = ops.rowsumsq_rstd(ss, D, 1e-6)
+    ref = qraw.clone()
+    ops.rmsnorm_rope_(ref, wq, 1e-6)
+    kbd = None if kb is None else kb.to(DEV)
+    two_pass = ops.attention(ref.view(B, Lq, H, dh), kvd[:, :, 0], kvd[:, :, 1], key_bias=kbd)
+    fused = ops.attention(qraw.view(B, Lq, H, dh), kvd[:, :, 0], kvd[:, :, 1], key_bias=kbd, q_norm=(rstd, wq, 1e-6))
+    check(fused, two_pass.float(), rel_l2=2e-3, maxrel=1.6e-2, what="short-key attention, q finished on load vs two passes")
+    fused_ss = ops.attention(qraw.view(B, Lq, H, dh), kvd[:, :, 0], kvd[:, :, 1], key_bias=kbd, q_norm=(ss, wq, 1e-6))
+    check(fused_ss, fused.float(), rel_l2=5e-4, maxrel=8e-3, what="short-key attention, partial sums vs row factor")
+
+
 def test_attention_fused_qkv_views_and_scale():
     """q/k/v as strided slices of one [B, N, 3, H, dh] projection buffer, custom softmax scale."""
     from ltxmi import ops
