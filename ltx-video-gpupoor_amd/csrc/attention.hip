@@ -506,13 +506,13 @@ extern "C" int ltxmi_attention_fwd_bf16(const ltxmi_attn_args* a, void* stream) 
     // where two blocks of accumulators do not fit the register file at 2 waves per SIMD)
     const int64_t wg256 = (int64_t)a->B * a->H * ((a->Lq + 255) / 256);
     if (a->head_dim == 64) {
+        // short key sequences (the T5 cross-attention): K / V resident in LDS, single-pass softmax (attention_cross.hip)
+        if (attn_cross_takes(a->B, a->H, a->Lq, a->Lk, a->head_dim)) return launch_attn_cross(p, s);
         // large self-attention: the software-pipelined LDS-DMA kernel (attention_pipe.hip)
         if (pipe_ok) {
             const int rc = launch_attn_pipe(p, s);
             if (rc != -1) return rc;
         }
-        // short key sequences (the T5 cross-attention): K / V resident in LDS, single-pass softmax (attention_cross.hip)
-        if (attn_cross_takes(a->B, a->H, a->Lq, a->Lk, a->head_dim)) return launch_attn_cross(p, s);
         if (wg256 >= 512 && !a->key_bias) return launch<64, false, ATTN_QB_BIG>(p, s);
         return a->key_bias ? launch<64, true, 1>(p, s) : launch<64, false, 1>(p, s);
     }
@@ -537,8 +537,8 @@ extern "C" int ltxmi_attention_kernel_id(int32_t B, int32_t H, int32_t Lq, int32
         if (span_ok && attn_pipe128_takes(B, H, Lq, Lk, head_dim, has_key_bias != 0)) return 6;
         return has_key_bias ? 5 : 4;
     }
-    if (span_ok && attn_pipe_takes(B, H, Lq, Lk, head_dim, has_key_bias != 0)) return 3;
     if (attn_cross_takes(B, H, Lq, Lk, head_dim)) return 7;
+    if (span_ok && attn_pipe_takes(B, H, Lq, Lk, head_dim, has_key_bias != 0)) return 3;
     const int64_t wg256 = (int64_t)B * H * ((Lq + 255) / 256);
     if (wg256 >= 512 && !has_key_bias) return 2;
     return has_key_bias ? 1 : 0;

@@ -17,11 +17,17 @@
 // lane, P^T straight from the accumulator registers into the PV product, V^T by transposed LDS reads, row sums on the matrix
 // pipe).  Two workgroups per CU (75 KB of LDS each); grid = B x H x G with G row groups per (batch, head) so that the chip's
 // 512 slots are filled once.
+#include <type_traits>
+
 #include "attention.h"
 
 namespace ltxmi {
 
 namespace cross {
+
+#ifndef LTXMI_XATTN_STAGGER
+#define LTXMI_XATTN_STAGGER 32        // x 64 cycles: how much later a CU's second resident workgroup starts its first iteration
+#endif
 
 constexpr int DH = 64;
 constexpr int KV_TILE = 64;
@@ -29,15 +35,19 @@ constexpr int MAX_TILES = 4;                         // <= 256 keys
 constexpr int ROW_BYTES = DH * 2;
 constexpr int TILE_BYTES = KV_TILE * DH * 2;         // 8 KiB: one K or V tile
 constexpr int K_OFF = 0, V_OFF = MAX_TILES * TILE_BYTES, BIAS_OFF = 2 * MAX_TILES * TILE_BYTES;
-constexpr int SCR_OFF = BIAS_OFF + MAX_TILES * KV_TILE * 4;
+constexpr int SCR_OFF = BIAS_OFF + MAX_TILES * KV_TILE * 16;           // 16 bytes per key: [bias hi, bias lo, 0 x 6] (bf16)
 constexpr int SCR_BYTES = 32 * 64;                   // per wave: 32 rows x 32 columns of bf16
-constexpr int SMEM = SCR_OFF + 4 * SCR_BYTES;        // 64 K + 1 K + 8 K = 74 752 B
+constexpr int QW_OFF = SCR_OFF + 4 * SCR_BYTES;       // this head's 64 q_norm weights (q finished on load)
+constexpr int SMEM = QW_OFF + DH * 2;                // 64 K + 4 K + 8 K + 128 B = 77 952 B
 constexpr int ROWS_PER_IT = 128;                     // 4 waves x 32 query rows
 constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ int k_swz(int row) { return (row >> 1) & 7; }
 
-__global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnParams p, int groups, int rows_per_group) {
+// NT = key tiles (ceil(Lk / 64), 1 .. 4): a compile-time constant, so that an iteration is one straight-line block hipcc can
+// schedule across (a run-time tile count put a wave-uniform branch around every tile's instructions)
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnParams p, int groups, int rows_per_group, int stagger_from) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -59,15 +69,14 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnParams p, int gr
     const uint16_t* kb_ = p.k + (int64_t)b * p.k_sb + head * DH;
     const uint16_t* vb = p.v + (int64_t)b * p.v_sb + head * DH;
     uint16_t* ob = p.o + (int64_t)b * p.o_sb + head * DH;
-    const int nt = (p.Lk + KV_TILE - 1) / KV_TILE;                          // 1 .. 4 (wave-uniform)
+    constexpr int nt = NT;
 
     // ---- K / V / bias -> LDS, all tiles at once.  Thread handles 16-byte chunks c = tid + 256 i of a [64][8] tile (attention.hip's
     // staging geometry); keys past Lk re-read the last key (finite data) and get a bias of -inf, i.e. P = 0.
     {
-        u32x4 kreg[MAX_TILES][2], vreg[MAX_TILES][2];
+        u32x4 kreg[NT][2], vreg[NT][2];
 #pragma unroll
-        for (int t = 0; t < MAX_TILES; ++t)
-            if (t < nt) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int c = tid + 256 * i;
@@ -78,13 +87,19 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnParams p, int gr
                 }
             }
         if (tid < MAX_TILES * KV_TILE) {
-            float bv = -INFINITY;
-            if (tid < p.Lk) bv = p.bias ? p.bias[(int64_t)b * p.bias_sb + tid] * LOG2E : 0.f;
-            *(float*)(smem + BIAS_OFF + tid * 4) = bv;
+            // The key bias rides on the QK^T product as one more k-step: K gets the columns [b', b' - bf16(b')] (hi + lo: exact to
+            // 2^-16 relative), Q the columns [1, 1], with b' = bias / softmax_scale so that c (K Q^T + b') = c K Q^T + bias log2(e).
+            // Keys past Lk get -1e30 (finite: -inf would meet the zero columns of Q as NaN), i.e. P = 0.
+            float bv = -1e30f;
+            if (tid < p.Lk) bv = p.bias ? p.bias[(int64_t)b * p.bias_sb + tid] * (LOG2E / p.scale_log2e) : 0.f;
+            const __bf16 hi = (__bf16)bv;
+            const __bf16 lo = (__bf16)(bv - (float)hi);
+            u32x4 w = {0u, 0u, 0u, 0u};
+            w[0] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+            *(u32x4*)(smem + BIAS_OFF + tid * 16) = w;
         }
 #pragma unroll
-        for (int t = 0; t < MAX_TILES; ++t)
-            if (t < nt) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int c = tid + 256 * i;
@@ -94,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnParams p, int gr
                 }
             }
     }
+    if (p.q_on_load() && tid < 8) *(u32x4*)(smem + QW_OFF + tid * 16) = *(const u32x4*)(p.q_w + head * DH + tid * 8);
     __syncthreads();                                   // the only barrier: from here on K / V / bias are read-only
 
     // ---- per-lane LDS read offsets (attention.hip)
@@ -110,32 +126,36 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnParams p, int gr
     const float c = p.scale_log2e;
     char* scr = smem + SCR_OFF + wave * SCR_BYTES;
 
-    // Q^T fragments of one iteration's rows, as loaded (the q-on-load arithmetic runs when the iteration starts)
-    auto load_q = [&](int it, bf16x8 (&raw)[4], int& q_ld) {
+    // ---- the Q pipeline.  An iteration's rows are requested one iteration ahead (raw, into qraw, with the row's RMSNorm
+    // factor when q is finished on load) and turned into the Q^T fragments qf in the MIDDLE of the iteration before theirs,
+    // right after the QK^T phase has read qf for the last time; the request for the iteration after goes out behind that.
+    // Where that wait sits matters: hipcc waits for vector memory with vmcnt(0) across the loop's back edge, i.e. for
+    // EVERYTHING outstanding.  At the top of an iteration that included the output stores issued a moment earlier (~2 us of
+    // HBM write latency exposed per iteration: 47 us per launch); in the middle, everything outstanding is half an iteration
+    // old or more.
+    bf16x8 qraw[4], qf[4];
+    float q_rstd = 0.f;
+    int q_ld = 0;
+    auto load_q = [&](int it) {
         const int row = row_begin + it * ROWS_PER_IT + wave * 32 + r;
         q_ld = row < p.Lq ? row : p.Lq - 1;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) raw[s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * hh);
+        for (int s = 0; s < 4; ++s) qraw[s] = *(const bf16x8*)(qb + (int64_t)q_ld * p.q_sl + 16 * s + 8 * hh);
+        if (p.q_on_load()) q_rstd = p.q_row_rstd(b, q_ld, p.H * DH);
     };
-    bf16x8 qraw[4];
-    int q_ld;
-    load_q(0, qraw, q_ld);
-
-    for (int it = 0; it < n_it; ++it) {
-        // ---- this iteration's Q^T fragments; optional q_norm (+ RoPE) on load with rmsnorm_rope_kernel's arithmetic (see
-        // attention_pipe.hip): x * rstd * weight, interleaved-pair rotation, ONE rounding to bf16
-        bf16x8 qf[4];
+    // qraw -> qf; optional q_norm (+ RoPE) with rmsnorm_rope_kernel's arithmetic (see attention_pipe.hip): x * rstd * weight,
+    // interleaved-pair rotation, ONE rounding to bf16
+    auto finish_q = [&]() {
         if (p.q_on_load()) {
-            const float rstd = p.q_row_rstd(b, q_ld, p.H * DH);
             const int64_t trow = (int64_t)b * p.rope_sb + (int64_t)q_ld * p.rope_sl;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int col = head * DH + 16 * s + 8 * hh;
-                const bf16x8 wv = *(const bf16x8*)(p.q_w + col);
+                const bf16x8 wv = *(const bf16x8*)(smem + QW_OFF + (16 * s + 8 * hh) * 2);
                 float o[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (float)qraw[s][e] * rstd * (float)wv[e];
+                for (int e = 0; e < 8; ++e) o[e] = (float)qraw[s][e] * q_rstd * (float)wv[e];
                 if (p.rope_cos) {
+                    const int col = head * DH + 16 * s + 8 * hh;
                     const bf16x8 cv = *(const bf16x8*)(p.rope_cos + trow + col), sv = *(const bf16x8*)(p.rope_sin + trow + col);
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
@@ -152,96 +172,132 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnParams p, int gr
 #pragma unroll
             for (int s = 0; s < 4; ++s) qf[s] = qraw[s];
         }
+    };
+    load_q(0);
+    finish_q();
+    if (n_it > 1) load_q(1);
+    // The two workgroups of a CU run the same program from the same start: both in their matrix phase, then both in their
+    // VALU phase.  The second resident (the dispatcher fills every CU once before it doubles up) starts half an iteration
+    // late, so that one's exp2 / cvt stream runs under the other's MFMAs.
+    if (blockIdx.x >= (unsigned)stagger_from) __builtin_amdgcn_s_sleep(LTXMI_XATTN_STAGGER);
+
+    for (int it = 0; it < n_it; ++it) {
         const int q0 = row_begin + it * ROWS_PER_IT + wave * 32;           // this wave's first row (wave-uniform)
 
-        // ---- S^T = K Q^T for every key tile: the whole score row of a query stays in registers
-        f32x16 sT[MAX_TILES][2];
-#pragma unroll
-        for (int t = 0; t < MAX_TILES; ++t)
-            if (t < nt) {
-                const char* ks = smem + K_OFF + t * TILE_BYTES;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) sT[t][kb][e] = 0.f;
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const bf16x8 kf = *(const bf16x8*)(ks + (kb ? k_rd1 : k_rd0) + (((2 * s4 + hh) ^ k_sw0) << 4));
-                        sT[t][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s4], sT[t][kb], 0, 0, 0);
-                    }
-                }
+        // ---- S'^T = K Q^T + b' for every key tile: the whole score row of a query stays in registers (NG accumulator tuples,
+        // never copied).  Five MFMAs per group of 32 keys -- the bias k-step, then the four of head_dim 64 -- with the next
+        // group's fragments requested behind the MFMA that frees their registers (hipcc left to itself read each K fragment
+        // right in front of its MFMA and waited for it).
+        constexpr int NG = 2 * NT;
+        f32x16 sT[NG];
+        bf16x8 kfr[5];                                   // [0] = the bias fragment, [1 + s4] = K, k-step s4
+        bf16x8 qaug;                                     // Q's side of the bias k-step: [1, 1, 0 ...] on the hh = 0 lanes
+        {
+            uint32_t w0 = hh == 0 ? 0x3f803f80u : 0u, w1 = 0u;
+            asm volatile("" : "+v"(w0), "+v"(w1));       // (made here every iteration: two registers less to keep across it)
+            const u32x4 w = {w0, w1, w1, w1};
+            qaug = __builtin_bit_cast(bf16x8, w);
+        }
+        auto read_k1 = [&](int g, int j) {
+            if (j == 0) {
+                kfr[0] = *(const bf16x8*)(smem + BIAS_OFF + (32 * g + r) * 16);
+            } else {
+                const char* ks = smem + K_OFF + (g >> 1) * TILE_BYTES + ((g & 1) ? k_rd1 : k_rd0);
+                kfr[j] = *(const bf16x8*)(ks + (((2 * (j - 1) + hh) ^ k_sw0) << 4));
             }
-        // the next iteration's Q rows: requested now, used ~2000 cycles from here
-        int q_ld_next = q_ld;
-        if (it + 1 < n_it) load_q(it + 1, qraw, q_ld_next);
-
-        // ---- scores -> log2 domain with the key bias; row maximum over all keys
+        };
+        auto max3 = [](float a, float b2, float c3) { return fmaxf(fmaxf(a, b2), c3); };
         float mt = -INFINITY;
+        auto group_max = [&](int g) {
+            const f32x16& x = sT[g];
+            const float a = max3(x[0], x[1], x[2]), b2 = max3(x[3], x[4], x[5]), c2 = max3(x[6], x[7], x[8]);
+            const float d2 = max3(x[9], x[10], x[11]), e2 = max3(x[12], x[13], x[14]);
+            mt = max3(max3(a, b2, c2), max3(d2, e2, x[15]), mt);
+            asm volatile("" : "+v"(mt));                 // (pinned under the next group's MFMAs)
+        };
 #pragma unroll
-        for (int t = 0; t < MAX_TILES; ++t)
-            if (t < nt) {
-                const float* bl = (const float*)(smem + BIAS_OFF) + t * KV_TILE;
+        for (int j = 0; j < 5; ++j) read_k1(0, j);
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+        for (int g = 0; g < NG; ++g) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 b4 = *(const f32x4*)(bl + 32 * kb + 8 * g + 4 * hh);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) sT[t][kb][4 * g + e] = __builtin_fmaf(sT[t][kb][4 * g + e], c, b4[e]);
-                    }
-                auto max3 = [](float a, float b2, float c3) { return fmaxf(fmaxf(a, b2), c3); };
-                float l1[11];
-#pragma unroll
-                for (int g = 0; g < 5; ++g) {
-                    l1[g] = max3(sT[t][0][3 * g], sT[t][0][3 * g + 1], sT[t][0][3 * g + 2]);
-                    l1[5 + g] = max3(sT[t][1][3 * g], sT[t][1][3 * g + 1], sT[t][1][3 * g + 2]);
+            for (int j = 0; j < 5; ++j) {
+                if (j == 0) {
+                    const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    sT[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0], qaug, z16, 0, 0, 0);
+                } else {
+                    sT[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[j], qf[j - 1], sT[g], 0, 0, 0);
                 }
-                l1[10] = max3(sT[t][0][15], sT[t][1][15], l1[0]);
-                const float a = max3(l1[1], l1[2], l1[3]), b2 = max3(l1[4], l1[5], l1[6]), c2 = max3(l1[7], l1[8], l1[9]);
-                mt = max3(mt, max3(a, b2, c2), l1[10]);
+                if (g + 1 < NG) read_k1(g + 1, j);         // the same fragment of the next group, five MFMAs ahead of its use
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (g >= 1) group_max(g - 1);                   // (VALU under the next group's MFMAs)
+        }
+        // qf has been read for the last time: the next iteration's fragments, then the request for the one after
+        if (it + 1 < n_it) finish_q();
+        if (it + 2 < n_it) load_q(it + 2);
+        group_max(NG - 1);
         {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
             mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
+        const float nmc = -mt * c;                           // P = 2^(c s' - c m): one FMA per score
         // (every key masked: the reference's softmax over a row of -10000s is uniform; here the bias is finite for every
         //  real key, so mt is finite whenever Lk >= 1)
 
         // ---- P = 2^(x - m), O^T += V^T P^T, l += sum P, tile by tile (a tile's score registers are dead after its P)
+        // (O^T and l start as the FIRST product's zero C operand: they become live when tile 0's 32 score registers have
+        // already turned into P -- zeroed up front they sat on top of all 128 scores and the kernel spilled)
         f32x16 oT[2];
-        f32x4 lT = {0.f, 0.f, 0.f, 0.f};
+        f32x4 lT;
+        const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        // Software-pipelined by hand like the first phase: step (t, sp) = 16 keys = one ones-MFMA + two PV MFMAs, with the V^T
+        // fragments of the NEXT step requested before them and one quarter of the NEXT tile's exp2 / cvt (8 scores -> one P
+        // fragment) behind them.  (Left to hipcc every PV MFMA waited out the LDS latency of the transposed reads issued right
+        // in front of it.)
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        auto read_v = [&](int t, int sp, bf16x8 (&dst)[2]) {
+            const char* vs = smem + V_OFF + t * TILE_BYTES + v_rd;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oT[d][e] = 0.f;
-#pragma unroll
-        for (int t = 0; t < MAX_TILES; ++t)
-            if (t < nt) {
-                bf16x8 pf[4];
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) sT[t][kb][e] = fast_exp2(sT[t][kb][e] - mt);
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) pf[2 * kb + h2][e] = (__bf16)sT[t][kb][8 * h2 + e];
-                }
-                const char* vs = smem + V_OFF + t * TILE_BYTES + v_rd;
-#pragma unroll
-                for (int sp = 0; sp < 4; ++sp) {
-                    lT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[sp], lT, 0, 0, 0);
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        const char* base = vs + (2 * sp * 2 + d) * 512;
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 2 * 512));
-                        typedef __attribute__((ext_vector_type(8))) short s16x8;
-                        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        oT[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf[sp], oT[d], 0, 0, 0);
-                    }
-                }
+            for (int d = 0; d < 2; ++d) {
+                const char* base = vs + (2 * sp * 2 + d) * 512;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 2 * 512));
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                dst[d] = __builtin_bit_cast(bf16x8, both);
             }
+        };
+        // P fragment sp' of tile t: scores 8 h2 .. 8 h2 + 7 of key block kb, sp' = 2 kb + h2
+        auto make_p = [&](int t, int sp2, bf16x8& dst) {
+            const f32x16& x = sT[2 * t + (sp2 >> 1)];
+            const f32x2 c2v = {c, c}, m2v = {nmc, nmc};
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                // (two scores per v_pk_fma_f32: the VALU port, not the matrix pipe, paces this phase)
+                const f32x2 y = f32x2{x[8 * (sp2 & 1) + e], x[8 * (sp2 & 1) + e + 1]} * c2v + m2v;
+                dst[e] = (__bf16)fast_exp2(y[0]);
+                dst[e + 1] = (__bf16)fast_exp2(y[1]);
+            }
+            asm volatile("" : "+v"(dst));                // (pinned: hipcc otherwise gathers the converts where it likes)
+        };
+        bf16x8 pfr[2][4], vfr[2][2];
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) make_p(0, sp, pfr[0][sp]);
+        read_v(0, 0, vfr[0]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+                const int st = 4 * t + sp;                             // step number: V buffers alternate by it
+                if (st + 1 < 4 * NT) read_v((st + 1) >> 2, (st + 1) & 3, vfr[(st + 1) & 1]);
+                const bf16x8& pf = pfr[t & 1][sp];
+                lT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, st == 0 ? z4 : lT, 0, 0, 0);
+                oT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[st & 1][0], pf, st == 0 ? z16 : oT[0], 0, 0, 0);
+                oT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[st & 1][1], pf, st == 0 ? z16 : oT[1], 0, 0, 0);
+                if (t + 1 < NT) make_p(t + 1, sp, pfr[(t + 1) & 1][sp]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 
         // ---- O = O^T / l: query r's sum sits in lane (r & 15), register (r >> 4).  The 32 x 64 block leaves in two halves of
         // 32 columns through the wave's 2-KB scratch: 16 bytes per lane, 16 whole 64-byte row halves per store instruction.
@@ -263,7 +319,6 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnParams p, int gr
                 if (q0 + row < row_end) *(u32x4*)(ob + p.o_row(q0 + row) + 32 * d + chunk * 8) = w;
             }
         }
-        q_ld = q_ld_next;
     }
 }
 
@@ -278,8 +333,6 @@ bool attn_cross_takes(int B, int H, int Lq, int Lk, int head_dim) {
 int launch_attn_cross(AttnParams p, hipStream_t stream) {
     const int n_cu = device_cu_count("ltxmi_attention_fwd_bf16");
     if (n_cu <= 0) return LTXMI_ERR_LAUNCH;
-    static unsigned long long lds_done = 0;
-    if (const int rc = reserve_lds((const void*)cross::attn_cross_kernel, cross::SMEM, &lds_done, "ltxmi_attention_fwd_bf16")) return rc;
     // row groups per (batch, head): fill the chip's 2 x CUs slots once, never below two iterations per workgroup
     const int slots = 2 * n_cu, bh = p.B * p.H;
     int groups = slots / bh;
@@ -290,7 +343,23 @@ int launch_attn_cross(AttnParams p, hipStream_t stream) {
     rows = (rows + cross::ROWS_PER_IT - 1) / cross::ROWS_PER_IT * cross::ROWS_PER_IT;
     groups = (p.Lq + rows - 1) / rows;
     const int64_t grid = (int64_t)bh * groups;
-    hipLaunchKernelGGL(cross::attn_cross_kernel, dim3((unsigned)grid), dim3(256), cross::SMEM, stream, p, groups, rows);
+    const int nt = (p.Lk + cross::KV_TILE - 1) / cross::KV_TILE;
+#define LTXMI_XATTN_LAUNCH(N)                                                                                              \
+    {                                                                                                                      \
+        static unsigned long long lds_done = 0;                                                                            \
+        if (const int rc = reserve_lds((const void*)cross::attn_cross_kernel<N>, cross::SMEM, &lds_done,                   \
+                                       "ltxmi_attention_fwd_bf16"))                                                        \
+            return rc;                                                                                                     \
+        hipLaunchKernelGGL(cross::attn_cross_kernel<N>, dim3((unsigned)grid), dim3(256), cross::SMEM, stream, p, groups,   \
+                           rows, n_cu);                                                                                    \
+    }
+    switch (nt) {
+        case 1: LTXMI_XATTN_LAUNCH(1) break;
+        case 2: LTXMI_XATTN_LAUNCH(2) break;
+        case 3: LTXMI_XATTN_LAUNCH(3) break;
+        default: LTXMI_XATTN_LAUNCH(4) break;
+    }
+#undef LTXMI_XATTN_LAUNCH
     return check_launch("ltxmi_attention_fwd_bf16");
 }
 
