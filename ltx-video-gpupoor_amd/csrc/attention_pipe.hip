@@ -532,18 +532,23 @@ __device__ __forceinline__ bool attn_pipe_item(const AttnParams& p, const int ti
     return false;
 }
 
-template <int OCC, bool QSCALED>
+// FORCE_EXACT (diagnostic, ltxmi_attn_args.force_exact): every item straight in the exact form -- an instance of its own,
+// chosen by the launcher.  (As a run-time branch in front of the normal run it made hipcc share state between the two forms of
+// the item: 157 spilled registers instead of 19, the launch twice as slow.)
+template <int OCC, bool QSCALED, bool FORCE_EXACT>
 __global__ __launch_bounds__(256, OCC) void attn_pipe_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    if (!p.force_exact) {                                                  // (a kernel argument: scalar, wave-uniform)
-        if (!attn_pipe_item<false, QSCALED>(p, tid, smem)) return;
-        if (p.redo_count != nullptr && tid == 0) atomicAdd(p.redo_count, 1u);
+    if (FORCE_EXACT) {
+        attn_pipe_item<true, QSCALED>(p, tid, smem);
+        return;
     }
+    if (!attn_pipe_item<false, QSCALED>(p, tid, smem)) return;
     // (rare) the item again, exact form throughout.  The thread id is laundered through an empty asm so that nothing the first
     // run derived from it is kept alive -- i.e. spilled -- across its loops for this path's sake: everything is recomputed.
     int tid2 = tid;
     asm volatile("" : "+v"(tid2));
+    if (p.redo_count != nullptr && tid2 == 0) atomicAdd(p.redo_count, 1u);
     attn_pipe_item<true, QSCALED>(p, tid2, smem);
 }
 
@@ -570,9 +575,10 @@ int launch_attn_pipe(AttnParams p, hipStream_t stream) {
     // the buffer descriptors address a (batch, head)'s K / V rows with 32-bit byte offsets
     if (!attn_pipe_span_ok(p.Lk, p.k_sl, p.v_sl, pipe::DH)) return -1;
     const bool qscaled = p.q_on_load();
-    auto kern = qscaled ? pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC, true> : pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC, false>;
-    static unsigned long long lds_done[2] = {0, 0};
-    if (const int rc = reserve_lds((const void*)kern, pipe::SMEM + 16, &lds_done[qscaled], "ltxmi_attention_fwd_bf16")) return rc;
+    auto kern = p.force_exact ? (qscaled ? pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC, true, true> : pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC, false, true>)
+                              : (qscaled ? pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC, true, false> : pipe::attn_pipe_kernel<LTXMI_ATTN_PIPE_OCC, false, false>);
+    static unsigned long long lds_done[4] = {0, 0, 0, 0};
+    if (const int rc = reserve_lds((const void*)kern, pipe::SMEM + 16, &lds_done[(p.force_exact ? 2 : 0) + qscaled], "ltxmi_attention_fwd_bf16")) return rc;
     p.q_tiles = (p.Lq + pipe::Q_PER_WG - 1) / pipe::Q_PER_WG;
     const int64_t grid = (int64_t)p.B * p.H * p.q_tiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), pipe::SMEM + 16, stream, p);
