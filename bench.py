@@ -419,8 +419,8 @@ def vae_decode_flop(grid):
     return 54.0 * sum(p * c for p, c in zip((s0, s1, s2, s3), per_pos))
 
 
-def _vae_traffic():
-    tpath = os.path.join(ROOT, "profiles", "traffic_vae.json")
+def _vae_traffic(tiled=False):
+    tpath = os.path.join(ROOT, "profiles", "traffic_vae_config5.json" if tiled else "traffic_vae.json")
     try:
         return json.load(open(tpath))
     except Exception:  # noqa: BLE001
@@ -504,9 +504,12 @@ def time_vae(device, iters, grid=GRID, z_tile=0):
             "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), "launch_ms": round(ms, 4), "launches_timed": len(conv_ms),
             "algorithmic_flop_per_launch": flop, "algorithmic_bytes_per_launch": byts,
-            "traffic": _vae_traffic().get("conv_direct_hbm_bytes_per_launch") if (not z_tile and tuple(grid) == GRID) else None,
-            "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/vae_time.py committed as " +
-                              _vae_traffic().get("source", "profiles/traffic_vae.json") + " (gfx950 corrections applied)",
+            "traffic": (_vae_traffic().get("conv_direct_hbm_bytes_per_launch") if (not z_tile and tuple(grid) == GRID) else
+                        _vae_traffic(True).get("conv_direct_hbm_bytes_per_launch") if (z_tile == 4 and tuple(grid) == (33, 23, 40))
+                        else None),
+            "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/vae_time.py (tools/vae_tiled_time.py "
+                              "for the z-tiled decode) committed as " +
+                              _vae_traffic(bool(z_tile)).get("source", "profiles/traffic_vae.json") + " (gfx950 corrections applied)",
             "hbm_side": {"bound": "hbm", "achieved": round(byts / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(byts / ms / 1e6 / HBM_PEAK_GBS, 4),
                          "note": "BASELINE.json calls this kernel HBM-bound; at 1728 FLOP/B it is not: both roofs reported"}}

@@ -281,6 +281,13 @@ typedef struct ltxmi_conv3d_args {
     const float* post_scale;   /* fp32 [B, Cout], or NULL together with post_shift          */
     const float* post_shift;
     float post_eps;            /* PixelNorm eps (pixel_norm.py: 1e-8)                       */
+    /* 0.5 (optional, NULL = off): with post_norm = 1, a SECOND output beside y.  y keeps the raw result (conv + bias + add,
+     * or the depth-to-space store with its residual) bit for bit as without post_norm; y_norm (y's shape) receives
+     * silu(pixelnorm(y) * (1 + post_scale[b]) + post_shift[b]) computed from y's bf16 values: the NEXT ResnetBlock3D's
+     * norm1 -> AdaLN -> SiLU (causal_video_autoencoder.py:1197-1224) or the decoder's tail (:771-795) without the launch that
+     * reads y back.  `add` with Cout == 128, or d2s with Cout == 1024 (post_scale / post_shift are [B, 128] then); ask
+     * ltxmi_conv3d_fuses_post_norm(). */
+    void* y_norm;
 } ltxmi_conv3d_args;
 
 /* Two implementations behind this entry, chosen by shape: a direct convolution with the input halo
@@ -289,7 +296,7 @@ typedef struct ltxmi_conv3d_args {
  * Requirements for both: Cin % 64 == 0, Cout % 8 == 0, 16-byte aligned x / w. */
 int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* args, void* stream);
 /* 1 if ltxmi_conv3d_ndhwc_bf16(args) with post_norm = 1 would apply it in its epilogue (the four-wave direct convolution
- * with Cout == 128, plain store, no `add`), 0 otherwise.  Reads the fields that choose the implementation (shape, flags, algo,
+ * with Cout == 128, plain store, no `add`; with y_norm set: `add` and Cout == 128, or d2s and Cout == 1024), 0 otherwise.  Reads the fields that choose the implementation (shape, flags, algo,
  * bias != NULL); no launch. */
 int ltxmi_conv3d_fuses_post_norm(const ltxmi_conv3d_args* args);
 

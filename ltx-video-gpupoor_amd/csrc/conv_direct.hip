@@ -25,7 +25,8 @@ struct ConvDirectP {
     int B, T, H, W, Cin, Cout;
     int tpad, pad_replicate, tzero;
     int tiles_t, tiles_y, tiles_x, tiles_n;
-    const float* post_scale; const float* post_shift; float post_eps;      // EPI 3 only
+    const float* post_scale; const float* post_shift; float post_eps;      // EPI >= 3 only
+    uint16_t* y2;                                                          // EPI 4 / 5: the activated second output
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page_cd[16];
@@ -502,7 +503,12 @@ __device__ __forceinline__ int swz(int c, int r) { return c ^ (((r >> 2) & 1) <<
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p) {
-    constexpr bool ADD = (EPI == 1), D2S = (EPI == 2), PNORM = (EPI == 3);
+    // EPI 4 / 5 = EPI 1 / 2 with TWO outputs: y as EPI 1 / 2 store it, and y2 = silu(pixelnorm(y) (1 + scale) + shift) computed from
+    // the bf16 values of y -- the next ResnetBlock3D's norm1 -> AdaLN -> SiLU (causal_video_autoencoder.py:1197-1224), or the
+    // decoder's tail (:771-795), without the launch that would read y back.  Needs all channels of an output position in one
+    // wave: Cout == 128 (EPI 4), Cout == 8 * 128 (EPI 5: a 128-column block is one (p1 p2 p3)).
+    constexpr bool DUAL = (EPI >= 4);
+    constexpr bool ADD = (EPI == 1 || EPI == 4), D2S = (EPI == 2 || EPI == 5), PNORM = (EPI == 3 || DUAL);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* wst = smem + HALO_BYTES;
@@ -712,11 +718,51 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
     if (PNORM) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const u32x2 bv = *(const u32x2*)(p.bias + j * 16 + ecol);
+            const u32x2 bv = *(const u32x2*)(p.bias + n0 + j * 16 + ecol);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 acc[i][j][0] += bf_lo(bv[0]); acc[i][j][1] += bf_hi(bv[0]);
                 acc[i][j][2] += bf_lo(bv[1]); acc[i][j][3] += bf_hi(bv[1]);
+            }
+        }
+        if (DUAL) {
+            // y exactly as EPI 1 / 2 store it, kept in the accumulators as bf16-representable floats: bf16(conv + bias) then
+            // + add in bf16 (EPI 1 rounds twice), or bf16(conv + bias + residual) (EPI 2 rounds once)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pos = wave * 64 + i * 16 + frow;
+                const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1), xx = min(x0 + (pos & 15), p.W - 1);
+                const int64_t prow = (((int64_t)b * p.T + t) * p.H + yy) * p.W + xx;
+                if (ADD) {
+                    u32x2 av[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[j] = *(const u32x2*)(p.add + prow * 128 + j * 16 + ecol);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t w0 = pack_bf16(acc[i][j][0], acc[i][j][1]), w1 = pack_bf16(acc[i][j][2], acc[i][j][3]);
+                        const uint32_t r0 = pack_bf16(bf_lo(w0) + bf_lo(av[j][0]), bf_hi(w0) + bf_hi(av[j][0]));
+                        const uint32_t r1 = pack_bf16(bf_lo(w1) + bf_lo(av[j][1]), bf_hi(w1) + bf_hi(av[j][1]));
+                        acc[i][j][0] = bf_lo(r0); acc[i][j][1] = bf_hi(r0);
+                        acc[i][j][2] = bf_lo(r1); acc[i][j][3] = bf_hi(r1);
+                    }
+                } else {
+                    const int pp = n0 >> 7;                                  // Cout / 8 == 128: this block is one (p1 p2 p3)
+                    const uint16_t* rrow = p.res ? p.res + prow * p.res_ch + pp : nullptr;
+                    const int cm = p.res_ch >> 3;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        if (rrow) {
+                            // (conv + bias) + residual in this order here and in EPI 2 (-ffast-math may re-associate otherwise)
+                            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += bf2f(rrow[((j * 16 + ecol + e) % cm) * 8]);
+                        }
+                        const uint32_t r0 = pack_bf16(v[0], v[1]), r1 = pack_bf16(v[2], v[3]);
+                        acc[i][j][0] = bf_lo(r0); acc[i][j][1] = bf_hi(r0);
+                        acc[i][j][2] = bf_lo(r1); acc[i][j][3] = bf_hi(r1);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -730,6 +776,72 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
             s2 += __shfl_xor(s2, 32, 64);
             rstd_i[i] = rsqrtf(s2 * (1.0f / 128.0f) + p.post_eps);
         }
+    }
+    if (DUAL) {
+        // two stores per 32 positions x 64 channels: the raw values, then the activated ones, through the same scratch (a wave's
+        // LDS operations complete in order)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 sc_v[4], sh_v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (p.post_scale) {
+                    sc_v[j] = *(const f32x4*)(p.post_scale + (int64_t)b * 128 + h * 64 + j * 16 + ecol);
+                    sh_v[j] = *(const f32x4*)(p.post_shift + (int64_t)b * 128 + h * 64 + j * 16 + ecol);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const int i = 2 * c + ii;
+                        const int row_l = ii * 16 + frow;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 a4 = acc[i][h * 4 + j];
+                            float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                            if (pass) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float u = v[e] * rstd_i[i];
+                                    if (p.post_scale) u = u * (1.0f + sc_v[j][e]) + sh_v[j][e];
+                                    v[e] = silu_f(u);
+                                }
+                            }
+                            u32x2 o;
+                            o[0] = pack_bf16(v[0], v[1]);
+                            o[1] = pack_bf16(v[2], v[3]);
+                            const int chunk = j * 2 + (lane >> 5);
+                            *(u32x2*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4) + ((lane >> 4) & 1) * 8) = o;
+                        }
+                    }
+                    uint16_t* dst = pass ? p.y2 : p.y;
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const int row_l = t4 * 8 + (lane >> 3), chunk = lane & 7;
+                        const u32x4 w = *(const u32x4*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4));
+                        const int pos = wave * 64 + c * 32 + row_l;
+                        const int t = t0 + (pos >> 7), yy = y0 + ((pos >> 4) & 7), xx = x0 + (pos & 15);
+                        if (t < p.T && yy < p.H && xx < p.W) {
+                            if (D2S) {
+                                const int pp = n0 >> 7;
+                                const int to = 2 * t + (pp >> 2) - 1, yo = 2 * yy + ((pp >> 1) & 1), xo = 2 * xx + (pp & 1);
+                                if (to >= 0) {
+                                    const int64_t opos = (((int64_t)b * (2 * p.T - 1) + to) * (2 * p.H) + yo) * (2 * p.W) + xo;
+                                    *(u32x4*)(dst + opos * 128 + h * 64 + chunk * 8) = w;
+                                }
+                            } else {
+                                const int64_t off = ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * 128 + h * 64 + chunk * 8;
+                                *(u32x4*)(dst + off) = w;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -775,6 +887,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
                         v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
                     }
                     if (D2S && p.res) {
+                        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));      // (conv + bias) + residual: see EPI 5
                         const int pos = wave * 64 + i * 16 + frow;
                         const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1);
                         const int xx = min(x0 + (pos & 15), p.W - 1);
@@ -847,10 +960,13 @@ static int64_t conv3d_direct_grid(const ltxmi_conv3d_args* a) {
 static bool conv3d_direct_four_wave_form(const ltxmi_conv3d_args* a, int64_t grid) {
     return a->Cout % 128 == 0 && grid < (1ll << 31) && ((a->algo != 4 && grid >= 768) || a->algo == 3);
 }
-// ltxmi_conv3d_fuses_post_norm: the four-wave form with ONE 128-channel block (a wave then holds every channel of its positions)
+// ltxmi_conv3d_fuses_post_norm: the four-wave form where a wave holds every channel of its output positions -- ONE 128-channel
+// block (plain store; with `add` only as the second output y_norm beside the raw y), or the depth-to-space store to 128 channels
+// (second output only: a 128-column block is one (p1 p2 p3))
 bool conv3d_direct_fuses_post_norm(const ltxmi_conv3d_args* a) {
-    return a->algo != 1 && conv3d_direct_takes(a) && a->Cout == 128 && !a->d2s && !a->add &&
-           conv3d_direct_four_wave_form(a, conv3d_direct_grid(a));
+    if (a->algo == 1 || !conv3d_direct_takes(a) || !conv3d_direct_four_wave_form(a, conv3d_direct_grid(a))) return false;
+    if (a->y_norm) return (a->d2s && a->Cout == 1024) || (!a->d2s && a->add && a->Cout == 128);
+    return a->Cout == 128 && !a->d2s && !a->add;
 }
 
 // Returns -1 when the shape is not one this kernel takes (the caller then uses the implicit GEMM).
@@ -866,6 +982,7 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     p.tiles_x = (a->W + CD_TX - 1) / CD_TX; p.tiles_n = (a->Cout + 127) / 128;
     const int64_t grid = (int64_t)a->B * p.tiles_t * p.tiles_y * p.tiles_x * p.tiles_n;
     p.post_scale = a->post_scale; p.post_shift = a->post_shift; p.post_eps = a->post_eps;
+    p.y2 = (uint16_t*)a->y_norm;
     if (a->post_norm && !conv3d_direct_fuses_post_norm(a)) return -1;
     if (conv3d_direct_four_wave_form(a, grid)) {
 #define LTXMI_CDV3_LAUNCH(E)                                                                                   \
@@ -877,7 +994,9 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
             hipLaunchKernelGGL(v3::conv3d_direct_v3_kernel<E>, dim3((unsigned)grid), dim3(256), v3::SMEM,      \
                                stream, p);                                                                     \
         }
-        if (a->d2s) LTXMI_CDV3_LAUNCH(2)
+        if (a->d2s && a->post_norm) LTXMI_CDV3_LAUNCH(5)
+        else if (a->add && a->post_norm) LTXMI_CDV3_LAUNCH(4)
+        else if (a->d2s) LTXMI_CDV3_LAUNCH(2)
         else if (a->add) LTXMI_CDV3_LAUNCH(1)
         else if (a->post_norm) LTXMI_CDV3_LAUNCH(3)
         else LTXMI_CDV3_LAUNCH(0)

@@ -1086,9 +1086,13 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
                       LTXMI_ERR_INVALID_ARG, "ltxmi_conv3d_ndhwc_bf16: post_norm must be 0 or 1, post_scale / post_shift both given or both NULL");
         LTXMI_REQUIRE((((uintptr_t)a->post_scale | (uintptr_t)a->post_shift) & 15) == 0, LTXMI_ERR_UNSUPPORTED,
                       "ltxmi_conv3d_ndhwc_bf16: misaligned post_scale / post_shift");
+        LTXMI_REQUIRE(((uintptr_t)a->y_norm & 15) == 0 && a->y_norm != a->y, LTXMI_ERR_INVALID_ARG,
+                      "ltxmi_conv3d_ndhwc_bf16: y_norm must be 16-byte aligned and distinct from y");
         LTXMI_REQUIRE(conv3d_direct_fuses_post_norm(a), LTXMI_ERR_UNSUPPORTED,
-                      "ltxmi_conv3d_ndhwc_bf16: post_norm is applied by the four-wave direct convolution with Cout == 128 only "
-                      "(ask ltxmi_conv3d_fuses_post_norm first)");
+                      "ltxmi_conv3d_ndhwc_bf16: post_norm is applied by the four-wave direct convolution where a wave holds all "
+                      "channels of a position (ask ltxmi_conv3d_fuses_post_norm first)");
+    } else {
+        LTXMI_REQUIRE(a->y_norm == nullptr, LTXMI_ERR_INVALID_ARG, "ltxmi_conv3d_ndhwc_bf16: y_norm without post_norm");
     }
     if (a->algo != 1) {
         const int rc = launch_conv3d_direct(a, (hipStream_t)stream);      // narrow stride-1 layers: direct convolution

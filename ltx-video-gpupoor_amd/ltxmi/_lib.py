@@ -51,7 +51,8 @@ class Conv3dArgs(ctypes.Structure):
                 ("res_channels", c_int), ("add", c_void_p),
                 ("stride_t", c_int), ("stride_hw", c_int), ("tpad", c_int), ("out_T", c_int),
                 ("kernel_t", c_int), ("time_pad_zeros", c_int), ("algo", c_int),
-                ("post_norm", c_int), ("post_scale", c_void_p), ("post_shift", c_void_p), ("post_eps", c_float)]
+                ("post_norm", c_int), ("post_scale", c_void_p), ("post_shift", c_void_p), ("post_eps", c_float),
+                ("y_norm", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/ltxmi.h one to one

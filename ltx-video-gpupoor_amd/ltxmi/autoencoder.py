@@ -148,14 +148,16 @@ class CausalConv3d(nn.Module):
         self._packed = None
         return super()._load_from_state_dict(*a, **k)
 
-    def forward(self, x, causal: bool = True, d2s=False, residual=None, add=None, tpad=0, out_T=0, post_norm=None):
+    def forward(self, x, causal: bool = True, d2s=False, residual=None, add=None, tpad=0, out_T=0, post_norm=None,
+                keep_raw=False):
         """x: NDHWC bf16.  post_norm = (scale, shift, eps): the PixelNorm -> AdaLN -> SiLU that follows this convolution
-        (ops.conv3d: in its epilogue where the kernel holds all channels of a position, a second launch otherwise)."""
+        (ops.conv3d: in its epilogue where the kernel holds all channels of a position, a second launch otherwise);
+        keep_raw: return (raw, activated)."""
         w, b = self.packed(d2s)
         if post_norm is not None and self.cout_padded != self.out_channels:
             raise ValueError("ltxmi.CausalConv3d: post_norm on a convolution with padded output channels")
         return ops.conv3d(x, w, b, causal, self.pad_replicate, d2s=d2s, residual=residual, add=add,
-                          stride=self.stride, tpad=tpad, out_T=out_T, post_norm=post_norm)
+                          stride=self.stride, tpad=tpad, out_T=out_T, post_norm=post_norm, keep_raw=keep_raw)
 
 
 def make_conv_nd(dims, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
@@ -207,16 +209,24 @@ class ResnetBlock3D(nn.Module):
         if timestep_conditioning:
             self.scale_shift_table = nn.Parameter(torch.randn(4, in_channels) / in_channels ** 0.5)
 
-    def forward(self, x, causal: bool = True, timestep=None):
-        """x NDHWC; timestep: the mid-block's embedding [B, 4C] (bf16) or None."""
+    def ada_values(self, B, timestep=None):
+        """(shift1, scale1, shift2, scale2), fp32 [B, C] each (None without timestep conditioning):
+        ada_values = table[None] + timestep.reshape(B, 4, C)  (:1211-1221)."""
+        if not self.timestep_conditioning:
+            return (None, None, None, None)
+        assert timestep is not None, "should pass timestep with timestep_conditioning=True"
+        ada = (self.scale_shift_table.float()[None] + timestep.float().reshape(B, 4, -1))
+        return tuple(t.contiguous() for t in ada.unbind(dim=1))
+
+    def forward(self, x, causal: bool = True, timestep=None, ada=None, x_act=None, next_norm=None):
+        """x NDHWC; timestep: the mid-block's embedding [B, 4C] (bf16) or None.
+        ada: ``ada_values`` worked out by the caller.  x_act: this block's norm1 -> AdaLN -> SiLU of x, already applied by the
+        producer of x (in its convolution's epilogue).  next_norm = (scale, shift, eps) of the norm that CONSUMES this block's
+        result (the next block's norm1, the decoder's tail): the block then returns (y, activated y), the second riding on
+        conv2's epilogue where the kernel can."""
         B = x.shape[0]
-        sc1 = sh1 = sc2 = sh2 = None
-        if self.timestep_conditioning:
-            assert timestep is not None, "should pass timestep with timestep_conditioning=True"
-            # ada_values = table[None] + timestep.reshape(B, 4, C)  (:1211-1221); [B,4,C] scalars
-            ada = (self.scale_shift_table.float()[None] + timestep.float().reshape(B, 4, -1))
-            sh1, sc1, sh2, sc2 = [t.contiguous() for t in ada.unbind(dim=1)]
-        h = ops.pixelnorm_ada_silu(x, sc1, sh1, apply_silu=True)
+        sh1, sc1, sh2, sc2 = self.ada_values(B, timestep) if ada is None else ada
+        h = x_act if x_act is not None else ops.pixelnorm_ada_silu(x, sc1, sh1, apply_silu=True)
         if self.inject_noise:
             h = self.conv1(h, causal=causal)
             h = h + self._spatial_noise(h, self.per_channel_scale1)
@@ -235,6 +245,8 @@ class ResnetBlock3D(nn.Module):
         if self.inject_noise:
             # conv2's noise (:1246) joins the skip tensor: conv2 + noise + skip is one sum, taken in conv2's epilogue
             s = s + self._spatial_noise(s, self.per_channel_scale2)
+        if next_norm is not None:
+            return self.conv2(h, causal=causal, add=s, post_norm=next_norm, keep_raw=True)
         return self.conv2(h, causal=causal, add=s)            # conv2 + skip add in one epilogue
 
     def _spatial_noise(self, like, per_channel_scale):
@@ -265,14 +277,25 @@ class UNetMidBlock3D(nn.Module):
                           inject_noise=inject_noise, timestep_conditioning=timestep_conditioning,
                           spatial_padding_mode=spatial_padding_mode) for _ in range(num_layers)])
 
-    def forward(self, x, causal: bool = True, timestep=None):
+    def plan(self, B, timestep=None):
+        """The blocks' AdaLN values for one forward (a list of ResnetBlock3D.ada_values): worked out ahead of the forward so
+        that the producer of this block's input can apply the first norm1 -> AdaLN -> SiLU itself."""
         temb = None
         if self.timestep_conditioning:
             assert timestep is not None, "should pass timestep with timestep_conditioning=True"
             temb = self.time_embedder(timestep.flatten().float())          # [B, 4C]
-        for blk in self.res_blocks:
-            x = blk(x, causal=causal, timestep=temb)
-        return x
+        return [blk.ada_values(B, temb) for blk in self.res_blocks]
+
+    def forward(self, x, causal: bool = True, timestep=None, plan=None, x_act=None, next_norm=None):
+        """plan / x_act / next_norm: see ResnetBlock3D.forward (x_act belongs to the first block, next_norm to the consumer of
+        the last block's result; with next_norm the result is (y, activated y))."""
+        adas = self.plan(x.shape[0], timestep) if plan is None else plan
+        n = len(self.res_blocks)
+        for i, blk in enumerate(self.res_blocks):
+            nn_ = (adas[i + 1][1], adas[i + 1][0], 1e-8) if i + 1 < n else next_norm
+            r = blk(x, causal=causal, ada=adas[i], x_act=x_act, next_norm=nn_)
+            x, x_act = r if nn_ is not None else (r, None)
+        return (x, x_act) if next_norm is not None else x
 
 
 class DepthToSpaceUpsample(nn.Module):
@@ -300,9 +323,16 @@ class DepthToSpaceUpsample(nn.Module):
         y = y.view(B, T, H, W, c, p1, p2, p3).permute(0, 1, 5, 2, 6, 3, 7, 4)
         return y.reshape(B, T * p1, H * p2, W * p3, c)
 
-    def forward(self, x, causal: bool = True):
+    def forward(self, x, causal: bool = True, next_norm=None):
+        """next_norm = (scale, shift, eps) of the norm that consumes the result: returns (y, activated y) then."""
         if self.stride == (2, 2, 2):
+            if next_norm is not None:
+                return self.conv(x, causal=causal, d2s=True, residual=x if self.residual else None, post_norm=next_norm,
+                                 keep_raw=True)
             return self.conv(x, causal=causal, d2s=True, residual=x if self.residual else None)
+        if next_norm is not None:
+            y = self.forward(x, causal=causal)
+            return y, ops.pixelnorm_ada_silu(y, next_norm[0], next_norm[1], True, next_norm[2])
         y = self._shuffle(self.conv(x, causal=causal))
         if self.stride[0] == 2:
             y = y[:, 1:]
@@ -490,18 +520,36 @@ class Decoder(nn.Module):
         if self.timestep_conditioning:
             assert timestep is not None, "should pass timestep with timestep_conditioning=True"
             scaled_t = timestep.to(torch.float32) * self.timestep_scale_multiplier.float()
-        for blk in self.up_blocks:
-            if self.timestep_conditioning and isinstance(blk, UNetMidBlock3D):
-                x = blk(x, causal=self.causal, timestep=scaled_t)
-            else:
-                x = blk(x, causal=self.causal)
         sc = sh = None
         if self.timestep_conditioning:
             emb = self.last_time_embedder(scaled_t.flatten())                    # [B, 2C]
             ada = self.last_scale_shift_table.float()[None] + emb.float().reshape(B, 2, -1)
             sh, sc = [t.contiguous() for t in ada.unbind(dim=1)]
-        x = ops.pixelnorm_ada_silu(x, sc, sh, apply_silu=True, out=x)
-        x = self.conv_out(x, causal=self.causal)
+        # Every PixelNorm -> AdaLN -> SiLU in front of a convolution is handed to the PRODUCER of its input as `next_norm`: the
+        # producer returns (raw, activated), from its own epilogue where its kernel holds all channels of a position (the
+        # 128-channel stage: 3 of the passes over the largest tensors of a decode), from a launch of its own otherwise.
+        blocks = list(self.up_blocks)
+        plans = {i: blk.plan(B, scaled_t if self.timestep_conditioning else None)
+                 for i, blk in enumerate(blocks) if isinstance(blk, UNetMidBlock3D)}
+        x_act = None
+        for i, blk in enumerate(blocks):
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+            if nxt is None:
+                nn_ = (sc, sh, 1e-8)
+            elif isinstance(nxt, UNetMidBlock3D):
+                nn_ = (plans[i + 1][0][1], plans[i + 1][0][0], 1e-8)
+            elif isinstance(nxt, ResnetBlock3D):
+                nn_ = (None, None, 1e-8)
+            else:
+                nn_ = None
+            if isinstance(blk, UNetMidBlock3D):
+                r = blk(x, causal=self.causal, plan=plans[i], x_act=x_act, next_norm=nn_)
+            elif isinstance(blk, ResnetBlock3D):
+                r = blk(x, causal=self.causal, x_act=x_act, next_norm=nn_)
+            else:
+                r = blk(x, causal=self.causal, next_norm=nn_)
+            x, x_act = r if nn_ is not None else (r, None)
+        x = self.conv_out(x_act, causal=self.causal)
         return ops.unpatchify_to_ncdhw(x, self.out_channels_rgb, self.patch_size)
 
 

@@ -373,17 +373,23 @@ CONV_ALGO = 0
 # conv3d(post_norm=...): let the convolution apply the PixelNorm -> AdaLN -> SiLU in its epilogue where it can (False: always
 # the second launch; the A/B switch of tools/vae_time.py --ab-post-norm and of the parity tests)
 CONV_POST_NORM_FUSE = True
+# conv3d(post_norm=..., keep_raw=True): the consumer's norm as a second output of the producing convolution where it can
+# (False: always the second launch; tools/vae_time.py --ab-second-output)
+CONV_SECOND_OUTPUT_FUSE = True
 
 
 def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, add=None, out=None,
-           stride=(1, 1, 1), tpad=0, out_T=0, kernel_t=3, time_pad_zeros=False, algo=None, post_norm=None):
+           stride=(1, 1, 1), tpad=0, out_T=0, kernel_t=3, time_pad_zeros=False, algo=None, post_norm=None, keep_raw=False):
     """x [B,T,H,W,Cin] NDHWC; w_packed [Cout, 27*Cin] (tap-major; (p1p2p3, c')-major rows when d2s).
     stride = (st, s, s) with st, s in {1, 2}; tpad / out_T: front time padding and output frames
     when they differ from CausalConv3d's (0 = default); kernel_t = 1: per-frame 3x3 Conv2d
     (w_packed [Cout, 9*Cin]); time_pad_zeros: nn.Conv3d zero padding in time.  See include/ltxmi.h.
     post_norm = (scale fp32 [B,Cout] or None, shift, eps): the result goes through PixelNorm -> (1+scale) x + shift -> SiLU
     (``pixelnorm_ada_silu``) -- in the convolution's epilogue where the kernel can (ltxmi_conv3d_fuses_post_norm), as a
-    second launch on the result otherwise."""
+    second launch on the result otherwise.
+    keep_raw (with post_norm): return (raw, activated) -- the raw result too, for the skip path of the block that consumes the
+    activated one (the NEXT block's norm1 -> AdaLN -> SiLU riding on this convolution: ltxmi_conv3d_args.y_norm); allowed
+    with `add` and with d2s."""
     _chk_bf16(x, w_packed, bias, residual, add, out)
     B, T, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
@@ -419,23 +425,31 @@ def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, a
             raise ValueError("ltxmi.conv3d: `add` must be a contiguous [B,T,H,W,Cout] tensor")
         a.add = add.data_ptr()
     second_launch = None
+    out_norm = None
+    if keep_raw and post_norm is None:
+        raise ValueError("ltxmi.conv3d: keep_raw is for post_norm")
     if post_norm is not None:
         scale, shift, eps = post_norm
-        if (scale is None) != (shift is None) or d2s or add is not None:
-            raise ValueError("ltxmi.conv3d: post_norm needs scale and shift together, and the plain store without `add`")
+        if (scale is None) != (shift is None) or ((d2s or add is not None) and not keep_raw):
+            raise ValueError("ltxmi.conv3d: post_norm needs scale and shift together, and (without keep_raw) the plain store "
+                             "without `add`")
+        c_norm = Cout // 8 if d2s else Cout
         for t in (scale, shift):
-            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.shape != (B, Cout) or not t.is_cuda):
-                raise ValueError("ltxmi.conv3d: post_norm scale / shift must be contiguous fp32 [B, Cout] device tensors")
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.shape != (B, c_norm) or not t.is_cuda):
+                raise ValueError("ltxmi.conv3d: post_norm scale / shift must be contiguous fp32 [B, C] device tensors")
         a.post_norm, a.post_scale, a.post_shift, a.post_eps = 1, _ptr(scale), _ptr(shift), eps
-        if not CONV_POST_NORM_FUSE or not lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)):
-            a.post_norm, a.post_scale, a.post_shift, a.post_eps = 0, None, None, 0.0
+        if keep_raw:
+            out_norm = torch.empty_like(out)
+            a.y_norm = out_norm.data_ptr()
+        if not (CONV_SECOND_OUTPUT_FUSE if keep_raw else CONV_POST_NORM_FUSE) or not lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)):
+            a.post_norm, a.post_scale, a.post_shift, a.post_eps, a.y_norm = 0, None, None, 0.0, None
             second_launch = (scale, shift, eps)
     tok = _prof_begin(("conv3d", B * oT * oH * oW, Cin, Cout, int(d2s)))
     check(lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), _stream()), "ltxmi_conv3d_ndhwc_bf16")
     _prof_end(tok)
     if second_launch is not None:
-        pixelnorm_ada_silu(out, second_launch[0], second_launch[1], True, second_launch[2], out=out)
-    return out
+        pixelnorm_ada_silu(out, second_launch[0], second_launch[1], True, second_launch[2], out=out_norm if keep_raw else out)
+    return (out, out_norm) if keep_raw else out
 
 
 def pixelnorm_ada_silu(x, scale=None, shift=None, apply_silu=True, eps=1e-8, out=None):

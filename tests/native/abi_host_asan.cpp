@@ -116,7 +116,8 @@ int main() {
     }
 
     if (ltxmi_attention_kernel_id(3, 32, 4992, 4992, 64, 0, 6144, 6144) != 3 || ltxmi_attention_kernel_id(1, 4, 100, 100, 64, 0, 768, 768) != 0 ||
-        ltxmi_attention_kernel_id(3, 32, 4992, 256, 64, 1, 4096, 4096) != 1 ||
+        ltxmi_attention_kernel_id(3, 32, 4992, 256, 64, 1, 4096, 4096) != 7 ||         // short key sequences: K / V resident in LDS
+        ltxmi_attention_kernel_id(3, 32, 512, 256, 64, 1, 4096, 4096) != 1 ||          // ... from 1024 query rows
         ltxmi_attention_kernel_id(1, 12, 32760, 32760, 128, 0, 4608, 4608) != 6 ||     // the head_dim-128 pipelined kernel
         ltxmi_attention_kernel_id(1, 2, 520, 520, 128, 0, 768, 768) != 4 || ltxmi_attention_kernel_id(1, 12, 32760, 512, 128, 1, 1536, 1536) != 5 ||
         // a token stride that puts a (batch, head)'s rows 2 GiB apart: the pipelined kernels hand the shape over, and the

@@ -958,6 +958,57 @@ def test_conv3d_post_norm_epilogue(cin, ada, causal):
     assert b"post_norm" in _lib.lib.ltxmi_last_error()
 
 
+@pytest.mark.parametrize("kind", ["add", "d2s_res", "d2s"])
+def test_conv3d_second_activated_output(kind):
+    """ltxmi_conv3d_args.y_norm (0.5): the NEXT block's norm1 -> AdaLN -> SiLU as a second output of conv2 + skip (Cout 128) and
+    of the depth-to-space store to 128 channels (causal_video_autoencoder.py:1197-1224, 771-795).  The raw output must be
+    bit-identical to the same call without post_norm; the activated one must equal ltxmi_pixelnorm_ada_silu_bf16 of it (same
+    fp32 arithmetic from the same bf16 values: at most a bf16 ulp apart).  Partial tiles on every axis, batch 2 with per-sample
+    scale / shift.  A width the kernel cannot fuse returns the same pair through the second launch."""
+    import ctypes
+    from ltxmi import ops, _lib
+    B, T, H, W = 2, 5, 20, 52
+    d2s = kind != "add"
+    cin, cout, c_out = (256, 1024, 128) if d2s else (128, 128, 128)
+    x = ndhwc(rnd(B, cin, T, H, W, seed=130)).to(DEV)
+    wp = rnd(cout, 27 * cin, seed=131, scale=(27 * cin) ** -0.5).to(DEV)
+    b = rnd(cout, seed=132).to(DEV)
+    add = None if d2s else ndhwc(rnd(B, cout, T, H, W, seed=133)).to(DEV)
+    res = x if kind == "d2s_res" else None
+    pn = (rnd(B, c_out, seed=134, scale=0.3).float().to(DEV), rnd(B, c_out, seed=135, scale=0.3).float().to(DEV), 1e-8)
+    a = _lib.Conv3dArgs()
+    a.bias, a.B, a.T, a.H, a.W, a.Cin, a.Cout, a.causal, a.pad_replicate, a.algo, a.d2s = b.data_ptr(), B, T, H, W, cin, cout, 1, 1, 3, int(d2s)
+    a.add = add.data_ptr() if add is not None else None
+    a.y_norm = x.data_ptr()                                  # (any non-NULL pointer: the query launches nothing)
+    assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 1
+    plain = ops.conv3d(x, wp, b, True, True, d2s=d2s, residual=res, add=add, algo=3)
+    raw, act = ops.conv3d(x, wp, b, True, True, d2s=d2s, residual=res, add=add, algo=3, post_norm=pn, keep_raw=True)
+    torch.cuda.synchronize()
+    assert raw.shape == plain.shape == act.shape
+    assert torch.equal(raw, plain), f"{kind}: the raw output changed with the second output switched on"
+    want = ops.pixelnorm_ada_silu(plain, pn[0], pn[1], True, 1e-8)
+    d = (act.float() - want.float()).abs()
+    tol = want.float().abs() * 2.0 ** -7 + 1e-6             # one bf16 ulp (fast-math reciprocal / exp in both)
+    assert bool((d <= tol).all()), f"{kind}: activated output off by up to {float((d - tol).max()):.3e} beyond a bf16 ulp"
+    assert float(d.max()) < 0.05 and float((act.float() - want.float()).norm() / want.float().norm()) < 2e-3
+    # no scale / shift (a ResnetBlock3D without timestep conditioning)
+    raw0, act0 = ops.conv3d(x, wp, b, True, True, d2s=d2s, residual=res, add=add, algo=3, post_norm=(None, None, 1e-8), keep_raw=True)
+    want0 = ops.pixelnorm_ada_silu(plain, None, None, True, 1e-8)
+    assert torch.equal(raw0, plain)
+    assert float((act0.float() - want0.float()).norm() / want0.float().norm()) < 2e-3
+    # the forms that cannot fuse: same pair, the norm as a launch of its own
+    a.algo = 4
+    assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 0
+    plain4 = ops.conv3d(x, wp, b, True, True, d2s=d2s, residual=res, add=add, algo=4)
+    raw4, act4 = ops.conv3d(x, wp, b, True, True, d2s=d2s, residual=res, add=add, algo=4, post_norm=pn, keep_raw=True)
+    assert torch.equal(raw4, plain4) and torch.equal(act4, ops.pixelnorm_ada_silu(plain4, pn[0], pn[1], True, 1e-8))
+    # the entry refuses y_norm without post_norm, and y_norm == y
+    a.algo, a.x, a.w, a.y, a.post_norm, a.y_norm = 3, x.data_ptr(), wp.data_ptr(), raw.data_ptr(), 0, act.data_ptr()
+    assert _lib.lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), None) == -1        # LTXMI_ERR_INVALID_ARG
+    a.post_norm, a.post_eps, a.y_norm = 1, 1e-8, raw.data_ptr()
+    assert _lib.lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), None) == -1
+
+
 @pytest.mark.parametrize("cin,residual,red", [(256, True, 2), (128, False, 1)])
 @pytest.mark.parametrize("algo", [4, 3])
 def test_conv3d_direct_path_depth_to_space(cin, residual, red, algo, monkeypatch):

@@ -25,5 +25,11 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/vaewrite" -o vaewrite --
 python3 "$ROOT/tools/pmc_traffic.py" "$(find "$OUT/vaefetch" -name '*counter_collection.csv' | head -1)" \
     "$(find "$OUT/vaewrite" -name '*counter_collection.csv' | head -1)" "$OUT/traffic_vae.json" "$OUT/${TAG}_pmc_traffic_vae.md" "profiles/${TAG}_pmc_traffic_vae.md" "python tools/vae_time.py 2 (VAE decode 768x512x97)"
 echo "vae traffic done"
-rm -rf "$OUT/attn" "$OUT/vae" "$OUT/vaepmc" "$OUT/vaefetch" "$OUT/vaewrite"
+# the same two passes over the z-tiled decode of config 5 (1280x720x257, tiles of 4 + 1 latent frames)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/vae5fetch" -o vae5fetch -- python3 "$ROOT/tools/vae_tiled_time.py" 1 > "$OUT/vae5fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/vae5write" -o vae5write -- python3 "$ROOT/tools/vae_tiled_time.py" 1 > "$OUT/vae5write.log" 2>&1
+python3 "$ROOT/tools/pmc_traffic.py" "$(find "$OUT/vae5fetch" -name '*counter_collection.csv' | head -1)" \
+    "$(find "$OUT/vae5write" -name '*counter_collection.csv' | head -1)" "$OUT/traffic_vae_config5.json" "$OUT/${TAG}_pmc_traffic_vae_config5.md" "profiles/${TAG}_pmc_traffic_vae_config5.md" "python tools/vae_tiled_time.py 1 (VAE decode 1280x720x257, z-tiled)"
+echo "vae config-5 traffic done"
+rm -rf "$OUT/attn" "$OUT/vae" "$OUT/vaepmc" "$OUT/vaefetch" "$OUT/vaewrite" "$OUT/vae5fetch" "$OUT/vae5write"
 ls -la "$OUT"

@@ -15,10 +15,13 @@
 #include <vector>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((address_space(1))) void* glb_ptr;
 
-template <int V, int THREADS>
+// SH = 1: the same 64 x 64 x 64 per wave and iteration as 2 x 2 blocks x 4 k-steps of v_mfma_f32_32x32x16_bf16 (16 MFMAs of 32
+// cycles instead of 32 of 16), the same 16 fragment reads
+template <int V, int THREADS, int SH = 0>
 __global__ __launch_bounds__(THREADS) void k(const uint32_t* __restrict__ rnd, float* out, unsigned long long* cyc, int iters, int salt) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -36,6 +39,10 @@ __global__ __launch_bounds__(THREADS) void k(const uint32_t* __restrict__ rnd, f
     f32x4 acc[4][4];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x16 acc32[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
     int b_off[4];
     constexpr int WOFF = THREADS == 512 ? 92160 : 32768;       // (the four-wave form's LDS is half the size)
     for (int j = 0; j < 4; ++j) b_off[j] = WOFF + (wn * 64 + j * 16 + frow) * 128 + ((fchunk ^ (frow & 7)) << 4);
@@ -51,11 +58,20 @@ __global__ __launch_bounds__(THREADS) void k(const uint32_t* __restrict__ rnd, f
         const char* ws = lds + ((n_off & 1) << 13);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (SH == 0) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[S][j][ks], af[S][i][ks], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[S][j][ks], af[S][i][ks], acc[i][j], 0, 0, 0);
+            } else {
+                // k-step i: fragments [i][block]
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                    for (int cj = 0; cj < 2; ++cj)
+                        acc32[pi][cj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[S][i][cj], af[S][i][pi], acc32[pi][cj], 0, 0, 0);
+            }
             if (V & 2) {
                 int row;
                 if (V & 4) {
@@ -96,20 +112,23 @@ __global__ __launch_bounds__(THREADS) void k(const uint32_t* __restrict__ rnd, f
     float sum = (float)ctl;
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int e = 0; e < 16; ++e) sum += acc32[i][j][e];
     out[blockIdx.x * THREADS + tid] = sum;
     if (lane == 0) cyc[blockIdx.x * (THREADS / 64) + wave] = t1 - t0;
 }
 
-template <int V, int THREADS = 512>
+template <int V, int THREADS = 512, int SH = 0>
 static void run(const uint32_t* rnd, float* out, unsigned long long* cyc, const char* what) {
     const int iters = 2048, grid = THREADS == 512 ? 256 : 512;      // one 8-wave workgroup or two 4-wave workgroups per CU
     const int smem = THREADS == 512 ? 147456 : 76800;
-    hipFuncSetAttribute((const void*)k<V, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute((const void*)k<V, THREADS, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k<V, THREADS>), dim3(grid), dim3(THREADS), smem, 0, rnd, out, cyc, iters, 5);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k<V, THREADS, SH>), dim3(grid), dim3(THREADS), smem, 0, rnd, out, cyc, iters, 5);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<V, THREADS>), dim3(grid), dim3(THREADS), smem, 0, rnd, out, cyc, iters, 5);
+    hipLaunchKernelGGL((k<V, THREADS, SH>), dim3(grid), dim3(THREADS), smem, 0, rnd, out, cyc, iters, 5);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -119,7 +138,7 @@ static void run(const uint32_t* rnd, float* out, unsigned long long* cyc, const 
     std::sort(h.begin(), h.end());
     const double cpi = (double)h[h.size() / 2] / iters;
     const double flop = 2.0 * 64 * 64 * 64 * (THREADS / 64) * grid * (double)iters;      // per wave and iteration: 64 x 64 x 64
-    printf("V=%2d x%d %-58s: %7.1f cycles / iteration (matrix pipe: 1024 per SIMD pair)  %6.3f ms  %6.0f TFLOP/s\n", V, THREADS / 64, what, cpi, ms, flop / ms / 1e9);
+    printf("%s V=%2d x%d %-58s: %7.1f cycles / iteration (matrix pipe: 1024 per SIMD pair)  %6.3f ms  %6.0f TFLOP/s\n", SH ? "32x32x16" : "16x16x32", V, THREADS / 64, what, cpi, ms, flop / ms / 1e9);
 }
 
 int main() {
@@ -146,5 +165,15 @@ int main() {
     run<31, 256>(rnd, out, cyc, "+ ~140 scalar instructions behind block 2");
     run<63, 256>(rnd, out, cyc, "+ two LDS-DMA pieces + vmcnt(0)");
     run<17, 256>(rnd, out, cyc, "bare MFMAs + scalar blob");
+    // the 32x32x16 shape: half the MFMA instructions for the same work
+    run<0, 512, 1>(rnd, out, cyc, "bare MFMAs");
+    run<3, 512, 1>(rnd, out, cyc, "+ 16 fragment reads per iteration");
+    run<15, 512, 1>(rnd, out, cyc, "+ addresses, s_barrier");
+    run<31, 512, 1>(rnd, out, cyc, "+ scalar chain");
+    run<63, 512, 1>(rnd, out, cyc, "+ two LDS-DMA pieces + vmcnt(0)");
+    run<0, 256, 1>(rnd, out, cyc, "bare MFMAs");
+    run<15, 256, 1>(rnd, out, cyc, "+ reads, addresses, s_barrier");
+    run<31, 256, 1>(rnd, out, cyc, "+ scalar chain");
+    run<63, 256, 1>(rnd, out, cyc, "+ two LDS-DMA pieces + vmcnt(0)");
     return 0;
 }

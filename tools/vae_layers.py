@@ -22,7 +22,8 @@ def wrap(name, fn):
         r = fn(*a, **k)
         e1.record()
         shapes = [tuple(t.shape) for t in list(a) + list(k.values()) if torch.is_tensor(t)][:3]
-        calls.append((name, shapes, {kk: vv for kk, vv in k.items() if not torch.is_tensor(vv) and vv is not None}, e0, e1))
+        calls.append((name, shapes, {kk: ("yes" if isinstance(vv, tuple) and any(torch.is_tensor(t) for t in vv) else vv)
+                                     for kk, vv in k.items() if not torch.is_tensor(vv) and vv is not None}, e0, e1))
         return r
     return inner
 

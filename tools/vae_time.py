@@ -2,7 +2,9 @@
 """VAE decode timing only (bench.py's time_vae), for A/B runs with LTXMI_LIB.
     python tools/vae_time.py [iters]
     python tools/vae_time.py --ab-post-norm [rounds]    in-process A/B: conv1's norm2 -> SiLU in the convolution's epilogue
-                                                        (ops.CONV_POST_NORM_FUSE) against the second launch, alternating decodes"""
+                                                        (ops.CONV_POST_NORM_FUSE) against the second launch, alternating decodes
+    python tools/vae_time.py --ab-second-output [rounds]   the same for the consumer's norm as a second output of conv2 + skip / of
+                                                        the depth-to-space store (ops.CONV_SECOND_OUTPUT_FUSE)"""
 import os
 import sys
 
@@ -11,7 +13,8 @@ for p in (ROOT, os.path.join(ROOT, "ltx-video-gpupoor_amd")):
     sys.path.insert(0, p)
 import bench  # noqa: E402
 
-if len(sys.argv) > 1 and sys.argv[1] == "--ab-post-norm":
+if len(sys.argv) > 1 and sys.argv[1] in ("--ab-post-norm", "--ab-second-output"):
+    knob = "CONV_POST_NORM_FUSE" if sys.argv[1] == "--ab-post-norm" else "CONV_SECOND_OUTPUT_FUSE"
     import torch
     import ltxmi
     from ltxmi import ops
@@ -20,7 +23,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--ab-post-norm":
     with torch.no_grad():
         for rnd_ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
             for fuse in (True, False):
-                ops.CONV_POST_NORM_FUSE = fuse
+                setattr(ops, knob, fuse)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 out = ltxmi.vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)
@@ -31,7 +34,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--ab-post-norm":
                 outs[fuse] = out
     med = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
     d = float((outs[True].float() - outs[False].float()).norm() / outs[False].float().norm())
-    print(f"decode 768x512x97: post_norm in conv1's epilogue {med[True]:.3f} ms | as a second launch {med[False]:.3f} ms "
+    print(f"decode 768x512x97: {knob} on {med[True]:.3f} ms | off (the norm as a launch of its own) {med[False]:.3f} ms "
           f"(x{med[False] / med[True]:.4f}); the two renderings differ by {d:.2e} relative L2", flush=True)
 else:
     print(bench.time_vae("cuda", int(sys.argv[1]) if len(sys.argv) > 1 else 5), flush=True)
