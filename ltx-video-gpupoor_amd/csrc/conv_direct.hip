@@ -708,63 +708,103 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
         if (total & 1) tap_body(s0_t{}, s1_t{});
     }
 
-    // ---- epilogue: 32 positions x 64 channels at a time through the wave's 4-KB LDS scratch (the halo is free)
+    // ---- epilogue.  A lane holds, per position block i, position wave * 64 + i * 16 + frow and, per channel block j, the channels
+    // j * 16 + ecol .. + 3: a position's 128 channels live in the four lanes frow, frow + 16, + 32, + 48.  Everything the
+    // epilogue reads from memory is requested up front (each dependent round trip -- a load behind a store behind a load -- costs
+    // the tile ~1 % of its time; round 3's form had one per 32 positions x 64 channels), the arithmetic runs on the accumulators in
+    // place, and 32 positions x 64 channels at a time go through the wave's 4-KB LDS scratch (the halo is free) so that every
+    // store instruction writes whole 128-byte rows.
     char* scr = smem + wave * 4096;
     const int ecol = (lane >> 4) * 4;
-    // EPI 3 (Cout == 128, so n0 == 0): PixelNorm over the 128 channels of a position -> (1 + scale) x + shift -> SiLU, from the
-    // fp32 accumulators.  A position's channels all live in this wave: 8 column blocks x 4 registers in each of the four lanes
-    // frow, frow + 16, + 32, + 48 -- the statistic is a lane-local sum and two cross-lane adds, no LDS exchange
+    const int Cp = D2S ? (p.Cout >> 3) : p.Cout, pp = D2S ? n0 / Cp : 0, cbase = n0 - pp * Cp;   // D2S: this block lies inside one (p1 p2 p3)
+    // per-channel operands (the block's 128 bias values; EPI >= 3: 128 scales and shifts) go through a 1.25-KB table in the wave's
+    // own LDS: one cooperative load, then 8- / 16-byte reads where they are used instead of registers held across the epilogue
+    char* tbl = smem + 16384 + wave * 2048;                               // [0, 512) scale, [512, 1024) shift, [1024, 1280) bias
+    if (PNORM && p.post_scale) {
+        const float* src = (lane < 32 ? p.post_scale : p.post_shift) + (int64_t)b * 128 + (lane & 31) * 4;
+        *(f32x4*)(tbl + lane * 16) = *(const f32x4*)src;
+    }
+    if (lane < 16) *(u32x4*)(tbl + 1024 + lane * 16) = *(const u32x4*)(p.bias + n0 + lane * 8);
+    int64_t prow[4];                                                       // input-grid position of (i, frow), clamped
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pos = wave * 64 + i * 16 + frow;
+        const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1), xx = min(x0 + (pos & 15), p.W - 1);
+        prow[i] = (((int64_t)b * p.T + t) * p.H + yy) * p.W + xx;
+    }
+    u32x4 add_v[2][2][4];                                                  // EPI 1: `add` in the stores' row-major layout
+    if (ADD && !DUAL) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int pos = wave * 64 + c * 32 + t4 * 8 + (lane >> 3);
+                    const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1), xx = min(x0 + (pos & 15), p.W - 1);
+                    const int n = min(n0 + h * 64 + (lane & 7) * 8, p.Cout - 8);
+                    add_v[h][c][t4] = *(const u32x4*)(p.add + ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.Cout + n);
+                }
+    }
+    u32x2 add_f[4][8];                                                     // EPI 4: `add` in the accumulators' layout
+    if (ADD && DUAL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) add_f[i][j] = *(const u32x2*)(p.add + prow[i] * 128 + j * 16 + ecol);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u32x2 bv = *(const u32x2*)(tbl + 1024 + (j * 16 + ecol) * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i][j][0] += bf_lo(bv[0]); acc[i][j][1] += bf_hi(bv[0]);
+            acc[i][j][2] += bf_lo(bv[1]); acc[i][j][3] += bf_hi(bv[1]);
+        }
+    }
+    if (D2S && p.res) {
+        // x_in = repeat(pixel_shuffle(x)): channel c' <- x[(c' mod (Cres/8)) * 8 + pp]   (gemm.hip, EPI_D2S); (conv + bias) + x_in
+        // in this order (-ffast-math may re-associate otherwise).  32-bit element offsets from the uniform base (launch: the
+        // tensor is below 2 GiB, Cres / 8 a power of two), one position block's 32 values in flight at a time
+        const uint32_t cmask = (uint32_t)(p.res_ch >> 3) - 1u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t rbase = (uint32_t)(prow[i] * p.res_ch + pp);
+            uint16_t rv[8][4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[j][e] = p.res[rbase + (((uint32_t)(cbase + j * 16 + ecol + e) & cmask) << 3)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                asm volatile("" : "+v"(acc[i][j]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] += bf2f(rv[j][e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (DUAL) {
+        // y exactly as EPI 1 / 2 store it, kept in the accumulators as bf16-representable floats: bf16(conv + bias) then + add in
+        // bf16 (EPI 1 rounds twice), or bf16(conv + bias + residual) (EPI 2 rounds once)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint32_t r0 = pack_bf16(acc[i][j][0], acc[i][j][1]), r1 = pack_bf16(acc[i][j][2], acc[i][j][3]);
+                if (ADD) {
+                    const u32x2 a2 = add_f[i][j];
+                    r0 = pack_bf16(bf_lo(r0) + bf_lo(a2[0]), bf_hi(r0) + bf_hi(a2[0]));
+                    r1 = pack_bf16(bf_lo(r1) + bf_lo(a2[1]), bf_hi(r1) + bf_hi(a2[1]));
+                }
+                acc[i][j][0] = bf_lo(r0); acc[i][j][1] = bf_hi(r0);
+                acc[i][j][2] = bf_lo(r1); acc[i][j][3] = bf_hi(r1);
+            }
+    }
+    // EPI >= 3 (128 channels per output position, all in this wave): PixelNorm -> (1 + scale) x + shift -> SiLU.  The statistic
+    // is a lane-local sum and two cross-lane adds, no LDS exchange
     float rstd_i[4];
     if (PNORM) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const u32x2 bv = *(const u32x2*)(p.bias + n0 + j * 16 + ecol);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][j][0] += bf_lo(bv[0]); acc[i][j][1] += bf_hi(bv[0]);
-                acc[i][j][2] += bf_lo(bv[1]); acc[i][j][3] += bf_hi(bv[1]);
-            }
-        }
-        if (DUAL) {
-            // y exactly as EPI 1 / 2 store it, kept in the accumulators as bf16-representable floats: bf16(conv + bias) then
-            // + add in bf16 (EPI 1 rounds twice), or bf16(conv + bias + residual) (EPI 2 rounds once)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int pos = wave * 64 + i * 16 + frow;
-                const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1), xx = min(x0 + (pos & 15), p.W - 1);
-                const int64_t prow = (((int64_t)b * p.T + t) * p.H + yy) * p.W + xx;
-                if (ADD) {
-                    u32x2 av[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) av[j] = *(const u32x2*)(p.add + prow * 128 + j * 16 + ecol);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint32_t w0 = pack_bf16(acc[i][j][0], acc[i][j][1]), w1 = pack_bf16(acc[i][j][2], acc[i][j][3]);
-                        const uint32_t r0 = pack_bf16(bf_lo(w0) + bf_lo(av[j][0]), bf_hi(w0) + bf_hi(av[j][0]));
-                        const uint32_t r1 = pack_bf16(bf_lo(w1) + bf_lo(av[j][1]), bf_hi(w1) + bf_hi(av[j][1]));
-                        acc[i][j][0] = bf_lo(r0); acc[i][j][1] = bf_hi(r0);
-                        acc[i][j][2] = bf_lo(r1); acc[i][j][3] = bf_hi(r1);
-                    }
-                } else {
-                    const int pp = n0 >> 7;                                  // Cout / 8 == 128: this block is one (p1 p2 p3)
-                    const uint16_t* rrow = p.res ? p.res + prow * p.res_ch + pp : nullptr;
-                    const int cm = p.res_ch >> 3;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                        if (rrow) {
-                            // (conv + bias) + residual in this order here and in EPI 2 (-ffast-math may re-associate otherwise)
-                            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += bf2f(rrow[((j * 16 + ecol + e) % cm) * 8]);
-                        }
-                        const uint32_t r0 = pack_bf16(v[0], v[1]), r1 = pack_bf16(v[2], v[3]);
-                        acc[i][j][0] = bf_lo(r0); acc[i][j][1] = bf_hi(r0);
-                        acc[i][j][2] = bf_lo(r1); acc[i][j][3] = bf_hi(r1);
-                    }
-                }
-            }
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float s2 = 0.f;
@@ -777,155 +817,62 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
             rstd_i[i] = rsqrtf(s2 * (1.0f / 128.0f) + p.post_eps);
         }
     }
-    if (DUAL) {
-        // two stores per 32 positions x 64 channels: the raw values, then the activated ones, through the same scratch (a wave's
-        // LDS operations complete in order)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f32x4 sc_v[4], sh_v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (p.post_scale) {
-                    sc_v[j] = *(const f32x4*)(p.post_scale + (int64_t)b * 128 + h * 64 + j * 16 + ecol);
-                    sh_v[j] = *(const f32x4*)(p.post_shift + (int64_t)b * 128 + h * 64 + j * 16 + ecol);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        const int i = 2 * c + ii;
-                        const int row_l = ii * 16 + frow;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const f32x4 a4 = acc[i][h * 4 + j];
-                            float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-                            if (pass) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    float u = v[e] * rstd_i[i];
-                                    if (p.post_scale) u = u * (1.0f + sc_v[j][e]) + sh_v[j][e];
-                                    v[e] = silu_f(u);
-                                }
-                            }
-                            u32x2 o;
-                            o[0] = pack_bf16(v[0], v[1]);
-                            o[1] = pack_bf16(v[2], v[3]);
-                            const int chunk = j * 2 + (lane >> 5);
-                            *(u32x2*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4) + ((lane >> 4) & 1) * 8) = o;
-                        }
-                    }
-                    uint16_t* dst = pass ? p.y2 : p.y;
-#pragma unroll
-                    for (int t4 = 0; t4 < 4; ++t4) {
-                        const int row_l = t4 * 8 + (lane >> 3), chunk = lane & 7;
-                        const u32x4 w = *(const u32x4*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4));
-                        const int pos = wave * 64 + c * 32 + row_l;
-                        const int t = t0 + (pos >> 7), yy = y0 + ((pos >> 4) & 7), xx = x0 + (pos & 15);
-                        if (t < p.T && yy < p.H && xx < p.W) {
-                            if (D2S) {
-                                const int pp = n0 >> 7;
-                                const int to = 2 * t + (pp >> 2) - 1, yo = 2 * yy + ((pp >> 1) & 1), xo = 2 * xx + (pp & 1);
-                                if (to >= 0) {
-                                    const int64_t opos = (((int64_t)b * (2 * p.T - 1) + to) * (2 * p.H) + yo) * (2 * p.W) + xo;
-                                    *(u32x4*)(dst + opos * 128 + h * 64 + chunk * 8) = w;
-                                }
-                            } else {
-                                const int64_t off = ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * 128 + h * 64 + chunk * 8;
-                                *(u32x4*)(dst + off) = w;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        u32x2 bias_v[4];
-        f32x4 sc_v[4], sh_v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!PNORM) bias_v[j] = *(const u32x2*)(p.bias + min(n0 + h * 64 + j * 16 + ecol, p.Cout - 4));
-            if (PNORM && p.post_scale) {
-                sc_v[j] = *(const f32x4*)(p.post_scale + (int64_t)b * 128 + h * 64 + j * 16 + ecol);
-                sh_v[j] = *(const f32x4*)(p.post_shift + (int64_t)b * 128 + h * 64 + j * 16 + ecol);
-            }
-        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            u32x4 add_v[4];
-            if (ADD) {
+#pragma unroll
+            for (int pass = 0; pass < (DUAL ? 2 : 1); ++pass) {
+                const bool activate = PNORM && (!DUAL || pass == 1);
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * c + ii;
+                    const int row_l = ii * 16 + frow;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 a4 = acc[i][h * 4 + j];
+                        float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                        if (activate) {
+                            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                            if (p.post_scale) {
+                                sc = *(const f32x4*)(tbl + (h * 64 + j * 16 + ecol) * 4);
+                                sh = *(const f32x4*)(tbl + 512 + (h * 64 + j * 16 + ecol) * 4);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e] * rstd_i[i] * (1.0f + sc[e]) + sh[e]);
+                        }
+                        u32x2 o;
+                        o[0] = pack_bf16(v[0], v[1]);
+                        o[1] = pack_bf16(v[2], v[3]);
+                        const int chunk = j * 2 + (lane >> 5);
+                        *(u32x2*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4) + ((lane >> 4) & 1) * 8) = o;
+                    }
+                }
+                uint16_t* dst = (DUAL && pass == 1) ? p.y2 : p.y;
 #pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4) {
-                    const int pos = wave * 64 + c * 32 + t4 * 8 + (lane >> 3);
-                    const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1), xx = min(x0 + (pos & 15), p.W - 1);
-                    const int n = min(n0 + h * 64 + (lane & 7) * 8, p.Cout - 8);
-                    add_v[t4] = *(const u32x4*)(p.add + ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.Cout + n);
-                }
-            }
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = 2 * c + ii;
-                const int row_l = ii * 16 + frow;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 a4 = acc[i][h * 4 + j];
-                    float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-                    if (PNORM) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float u = v[e] * rstd_i[i];
-                            if (p.post_scale) u = u * (1.0f + sc_v[j][e]) + sh_v[j][e];
-                            v[e] = silu_f(u);
+                    const int row_l = t4 * 8 + (lane >> 3), chunk = lane & 7;
+                    u32x4 w = *(const u32x4*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4));
+                    const int pos = wave * 64 + c * 32 + row_l;
+                    const int t = t0 + (pos >> 7), yy = y0 + ((pos >> 4) & 7), xx = x0 + (pos & 15);
+                    if (D2S) {
+                        // weight rows are packed (p1 p2 p3)-major: the 128 columns of this block are one pp
+                        const int cp = cbase + h * 64 + chunk * 8;
+                        const int to = 2 * t + (pp >> 2) - 1, yo = 2 * yy + ((pp >> 1) & 1), xo = 2 * xx + (pp & 1);
+                        if (t < p.T && yy < p.H && xx < p.W && to >= 0) {          // the first upsampled frame is dropped
+                            const int64_t opos = (((int64_t)b * (2 * p.T - 1) + to) * (2 * p.H) + yo) * (2 * p.W) + xo;
+                            *(u32x4*)(dst + opos * Cp + cp) = w;
                         }
-                    } else {
-                        v[0] += bf_lo(bias_v[j][0]); v[1] += bf_hi(bias_v[j][0]);
-                        v[2] += bf_lo(bias_v[j][1]); v[3] += bf_hi(bias_v[j][1]);
-                    }
-                    if (D2S && p.res) {
-                        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));      // (conv + bias) + residual: see EPI 5
-                        const int pos = wave * 64 + i * 16 + frow;
-                        const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1);
-                        const int xx = min(x0 + (pos & 15), p.W - 1);
-                        const int Cp = p.Cout >> 3, pp = n0 / Cp, cp = n0 - pp * Cp + h * 64 + j * 16 + ecol;
-                        const uint16_t* rrow = p.res + ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.res_ch + pp;
-                        const int cm = p.res_ch >> 3;
+                    } else if (t < p.T && yy < p.H && xx < p.W && n0 + h * 64 + chunk * 8 < p.Cout) {
+                        const int64_t off = ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.Cout + n0 + h * 64 + chunk * 8;
+                        if (ADD && !DUAL) {
+                            const u32x4 r = add_v[h][c][t4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += bf2f(rrow[((cp + e) % cm) * 8]);
+                            for (int e = 0; e < 4; ++e)
+                                w[e] = pack_bf16(bf_lo(w[e]) + bf_lo(r[e]), bf_hi(w[e]) + bf_hi(r[e]));
+                        }
+                        *(u32x4*)(dst + off) = w;
                     }
-                    u32x2 o;
-                    o[0] = pack_bf16(v[0], v[1]);
-                    o[1] = pack_bf16(v[2], v[3]);
-                    const int chunk = j * 2 + (lane >> 5);
-                    *(u32x2*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4) + ((lane >> 4) & 1) * 8) = o;
-                }
-            }
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const int row_l = t4 * 8 + (lane >> 3), chunk = lane & 7;
-                u32x4 w = *(const u32x4*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4));
-                const int pos = wave * 64 + c * 32 + row_l;
-                const int t = t0 + (pos >> 7), yy = y0 + ((pos >> 4) & 7), xx = x0 + (pos & 15);
-                if (D2S) {
-                    const int Cp = p.Cout >> 3, pp = n0 / Cp, cp = n0 - pp * Cp + h * 64 + chunk * 8;
-                    const int to = 2 * t + (pp >> 2) - 1, yo = 2 * yy + ((pp >> 1) & 1), xo = 2 * xx + (pp & 1);
-                    if (t < p.T && yy < p.H && xx < p.W && to >= 0) {
-                        const int64_t opos = (((int64_t)b * (2 * p.T - 1) + to) * (2 * p.H) + yo) * (2 * p.W) + xo;
-                        *(u32x4*)(p.y + opos * Cp + cp) = w;
-                    }
-                } else if (t < p.T && yy < p.H && xx < p.W && n0 + h * 64 + chunk * 8 < p.Cout) {
-                    const int64_t off = ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.Cout + n0 + h * 64 + chunk * 8;
-                    if (ADD) {
-                        const u32x4 r = add_v[t4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            w[e] = pack_bf16(bf_lo(w[e]) + bf_lo(r[e]), bf_hi(w[e]) + bf_hi(r[e]));
-                    }
-                    *(u32x4*)(p.y + off) = w;
                 }
             }
         }
@@ -950,6 +897,8 @@ static bool conv3d_direct_takes(const ltxmi_conv3d_args* a) {
     if (a->Cin % 64 != 0 || a->Cout % 8 != 0 || !a->bias) return false;
     if ((int64_t)a->B * a->T * a->H * a->W * a->Cin * 2 >= 0x7ffffff0ll) return false;   // halo rows are addressed with 32-bit byte offsets
     if (a->d2s && (a->Cout % 1024 != 0 || a->add)) return false;       // a 128-column block must be one (p1 p2 p3)
+    // the residual's channel wrap (c' mod Cres/8) is a mask in the four-wave form
+    if (a->d2s && a->residual && (a->res_channels < 8 || ((a->res_channels >> 3) & ((a->res_channels >> 3) - 1)) != 0)) return false;
     return true;
 }
 static int64_t conv3d_direct_grid(const ltxmi_conv3d_args* a) {

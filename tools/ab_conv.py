@@ -30,7 +30,10 @@ def main():
     shapes = [(97, 128, 192, 128, 128, 0, 1, "128->128 +skip (x4: 8.0 ms)"), (49, 64, 96, 256, 256, 0, 0, "256->256 (x4: 3.8 ms)"),
               (49, 64, 96, 256, 1024, 1, 0, "256->1024 d2s (4.1 ms)"), (25, 32, 48, 512, 512, 0, 1, "512->512 +skip (x4: 2.2 ms)"),
               (25, 32, 48, 512, 2048, 1, 0, "512->2048 d2s (2.0 ms)"), (13, 16, 24, 1024, 1024, 0, 0, "1024->1024 (x4: 1.5 ms)"),
-              (13, 16, 24, 1024, 4096, 1, 0, "1024->4096 d2s (1.5 ms)"), (97, 128, 192, 128, 48, 0, 0, "conv_out 128->48 (1.25 ms)")]
+              (13, 16, 24, 1024, 4096, 1, 0, "1024->4096 d2s (1.5 ms)"), (97, 128, 192, 128, 48, 0, 0, "conv_out 128->48 (1.25 ms)"),
+              # outside the sum: the epilogues with the PixelNorm -> AdaLN -> SiLU (post_norm; "+ y_norm": the raw result too)
+              (97, 128, 192, 128, 128, 0, 0, "128->128 post_norm"), (97, 128, 192, 128, 128, 0, 1, "128->128 +skip + y_norm"),
+              (49, 64, 96, 256, 1024, 1, 0, "256->1024 d2s + y_norm")]
     stream = torch.cuda.current_stream().cuda_stream
     total = [0.0] * len(libs)
     for (T, H, W, cin, cout, d2s, add, name) in shapes:
@@ -47,6 +50,13 @@ def main():
             a.residual, a.res_channels = x.data_ptr(), cin
         if add:
             a.add = skip.data_ptr()
+        if "post_norm" in name or "y_norm" in name:
+            cn = cout // 8 if d2s else cout
+            sc, sh = torch.randn(1, cn, device="cuda") * 0.3, torch.randn(1, cn, device="cuda") * 0.3
+            a.post_norm, a.post_scale, a.post_shift, a.post_eps = 1, sc.data_ptr(), sh.data_ptr(), 1e-8
+            if "y_norm" in name:
+                y2 = torch.empty_like(y)
+                a.y_norm = y2.data_ptr()
         times = [[] for _ in libs]
         ref = None
         for rep in range(6):
@@ -68,7 +78,7 @@ def main():
                 if rep > 0:
                     times[i].append(e0.elapsed_time(e1) / 5)
         med = [sorted(t)[len(t) // 2] for t in times]
-        mult = 4 if "x4" in name else 1
+        mult = 4 if "x4" in name else (0 if "norm" in name else 1)
         for i, m in enumerate(med):
             total[i] += mult * m
         flop = 2.0 * T * H * W * cout * 27 * cin
