@@ -20,7 +20,7 @@
  *   - argument structs (ltxmi_*_args) MUST be zero-initialised before the fields in use are
  *     set (`ltxmi_gemm_args a = {0};` / memset): versions append optional fields at the tail
  *     (0.2: rowsumsq*, a_kblock* of ltxmi_gemm_args; q_rowsumsq*, q_norm*, rope_*, o_segment*
- *     of ltxmi_attn_args; 0.3: q_rstd*; 0.4: conv3d post_*; 0.5: redo_counter, force_exact of ltxmi_attn_args), and a zero there means "off".  A caller must be
+ *     of ltxmi_attn_args; 0.3: q_rstd*; 0.4: conv3d post_*; 0.5: redo_counter, force_exact of ltxmi_attn_args, y_norm of ltxmi_conv3d_args), and a zero there means "off".  A caller must be
  *     rebuilt against the header of the library it loads.  An optional pointer that is NULL
  *     switches its companion size / stride fields off whatever they hold.
  */
