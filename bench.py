@@ -427,7 +427,7 @@ def _vae_traffic(tiled=False):
         return {}
 
 
-def time_vae(device, iters, grid=GRID, z_tile=0):
+def time_vae(device, iters, grid=GRID, z_tile=0, cross_check=True):
     """CausalVideoAutoencoder.decode of z [1,128,*grid] with the decoder of make_vae.
     z_tile > 0: the reference's z-tiling (vae.py:365-402, tiles of z_tile + 1 latent frames, blends).
     The untiled result is cross-checked against the same decode with every convolution as an implicit GEMM
@@ -439,7 +439,9 @@ def time_vae(device, iters, grid=GRID, z_tile=0):
     with torch.no_grad():
         img = ltxmi.vae_decode(z, vae, True, vae_per_channel_normalize=True, timestep=ts)
         assert torch.isfinite(img.float()).all(), "non-finite VAE decode output"
-        if not z_tile:
+        if not cross_check:
+            check = {"cross_check": "skipped (profiling run: the implicit-GEMM rendering would show up in the kernel statistics)"}
+        elif not z_tile:
             old = ops.CONV_ALGO
             try:
                 ops.CONV_ALGO = 1
@@ -476,7 +478,9 @@ def time_vae(device, iters, grid=GRID, z_tile=0):
         torch.cuda.synchronize()
         # the dominant convolution launch (128 -> 128 at the full-resolution stage: 4 per decode / per tile)
         pos3 = vae_stage_positions((z_tile + 1,) + tuple(grid[1:]) if z_tile else grid)[3]
-        key_conv = ("conv3d", pos3, 128, 128, 0)
+        # (conv1 of the two ResnetBlock3Ds there: the plain convolution + bias with norm2 -> SiLU in its epilogue; conv2's
+        # launches carry the skip add and a second, activated output on top and are not averaged in)
+        key_conv = ("conv3d", pos3, 128, 128, 0, "post_norm")
         ops.watch_launches([key_conv])
         times = []
         for _ in range(iters):
@@ -500,7 +504,8 @@ def time_vae(device, iters, grid=GRID, z_tile=0):
         flop = 54.0 * 128 * 128 * pos3
         byts = (128 + 128) * pos3 * 2 + 27 * 128 * 128 * 2
         out["roofline_conv"] = {
-            "kernel": f"conv3d_direct_v3_kernel (CausalConv3d 128 -> 128 at {pos3} positions, the full-resolution stage)",
+            "kernel": f"conv3d_direct_v3_kernel<3> (CausalConv3d 128 -> 128 at {pos3} positions, the full-resolution stage; "
+                      "norm2 -> AdaLN -> SiLU in its epilogue)",
             "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), "launch_ms": round(ms, 4), "launches_timed": len(conv_ms),
             "algorithmic_flop_per_launch": flop, "algorithmic_bytes_per_launch": byts,

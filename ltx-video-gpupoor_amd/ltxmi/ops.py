@@ -30,7 +30,7 @@ _events = {}
 
 def watch_launches(keys):
     """keys: iterable of ("gemm", M, N, K, epilogue) / ("attention", B, H, Lq, Lk, dh) /
-    ("conv3d", output positions, Cin, Cout, d2s) tuples, or None."""
+    ("conv3d", output positions, Cin, Cout, d2s[, "plain" | "add" | "post_norm" | "second_output"]) tuples, or None."""
     global _watch
     _watch = set(keys) if keys else None
     _events.clear()
@@ -52,9 +52,13 @@ def launch_times_ms():
     return {k: [a.elapsed_time(b) for a, b in v] for k, v in _events.items()}
 
 
-def _prof_begin(key):
-    if _watch is None or key not in _watch:
+def _prof_begin(key, key2=None):
+    if _watch is None:
         return None
+    if key not in _watch:
+        if key2 is None or key2 not in _watch:
+            return None
+        key = key2
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     return key, e0, e1
@@ -444,7 +448,9 @@ def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, a
         if not (CONV_SECOND_OUTPUT_FUSE if keep_raw else CONV_POST_NORM_FUSE) or not lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)):
             a.post_norm, a.post_scale, a.post_shift, a.post_eps, a.y_norm = 0, None, None, 0.0, None
             second_launch = (scale, shift, eps)
-    tok = _prof_begin(("conv3d", B * oT * oH * oW, Cin, Cout, int(d2s)))
+    # (watched either by shape alone or by shape + epilogue: "plain" / "add" / "post_norm" / "second_output")
+    kind = ("second_output" if a.y_norm else "post_norm") if a.post_norm else ("add" if add is not None else "plain")
+    tok = _prof_begin(("conv3d", B * oT * oH * oW, Cin, Cout, int(d2s)), ("conv3d", B * oT * oH * oW, Cin, Cout, int(d2s), kind))
     check(lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), _stream()), "ltxmi_conv3d_ndhwc_bf16")
     _prof_end(tok)
     if second_launch is not None:

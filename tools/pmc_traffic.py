@@ -52,7 +52,9 @@ def main():
         out["attention_hbm_bytes_per_launch"] = max(att, key=lambda r: r["launches"])["hbm_bytes_per_launch"]
     # the VAE legs' roofline kernel: the direct convolution with the plain store and the largest grid (128 -> 128 at the
     # full-resolution stage)
-    cv = [r for r in rows if "conv3d_direct_v3_kernel<0>" in r["kernel"]] or [r for r in rows if "conv3d_direct_kernel<0>" in r["kernel"]]
+    # (conv1 of a ResnetBlock3D there: epilogue 3 = bias + norm2 -> SiLU; the plain-store instance is the fallback)
+    cv = ([r for r in rows if "conv3d_direct_v3_kernel<3>" in r["kernel"]] or [r for r in rows if "conv3d_direct_v3_kernel<0>" in r["kernel"]]
+          or [r for r in rows if "conv3d_direct_kernel<0>" in r["kernel"]])
     if cv:
         out["conv_direct_hbm_bytes_per_launch"] = max(cv, key=lambda r: int(r["grid"] or 0))["hbm_bytes_per_launch"]
     out["source"] = sys.argv[5] if len(sys.argv) > 5 else sys.argv[4]

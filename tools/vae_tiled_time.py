@@ -8,4 +8,5 @@ for p in (ROOT, os.path.join(ROOT, "ltx-video-gpupoor_amd")):
     sys.path.insert(0, p)
 import bench  # noqa: E402
 
-print(bench.time_vae("cuda", int(sys.argv[1]) if len(sys.argv) > 1 else 2, grid=(33, 23, 40), z_tile=4), flush=True)
+print(bench.time_vae("cuda", int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2, grid=(33, 23, 40), z_tile=4,
+                     cross_check=sys.argv[-1] != "--no-check"), flush=True)

@@ -37,4 +37,6 @@ if len(sys.argv) > 1 and sys.argv[1] in ("--ab-post-norm", "--ab-second-output")
     print(f"decode 768x512x97: {knob} on {med[True]:.3f} ms | off (the norm as a launch of its own) {med[False]:.3f} ms "
           f"(x{med[False] / med[True]:.4f}); the two renderings differ by {d:.2e} relative L2", flush=True)
 else:
-    print(bench.time_vae("cuda", int(sys.argv[1]) if len(sys.argv) > 1 else 5), flush=True)
+    # --no-check (last argument): without the implicit-GEMM rendering bench.py compares the decode with (for profiler runs)
+    nocheck = sys.argv[-1] == "--no-check"
+    print(bench.time_vae("cuda", int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5, cross_check=not nocheck), flush=True)
