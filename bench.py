@@ -31,6 +31,7 @@ The JSON line also carries:
 Every extra leg checks its output (finite + a band of rows / a second implementation) before it reports a time.
 """
 import argparse
+import threading
 import json
 import os
 import sys
@@ -758,6 +759,11 @@ def main():
                          "this is `value`); ulysses: ONE video, tokens sharded over the ranks, all-to-all inside "
                          "self-attention (ltxmi.distributed, strong scaling); both (default): `value` from replicas and "
                          "the Ulysses run reported in the same line under \"ulysses\"")
+    ap.add_argument("--collective-timeout", type=float, default=300.0,
+                    help="N > 1: seconds the legs that run collectives (Ulysses at two sizes, the tile-parallel VAE decode) may "
+                         "take together before a watchdog prints the line with the replicas measurement and an error entry for "
+                         "them, and ends the ranks (they could only be run at world size 1 on hardware so far: a hang there "
+                         "must not take the headline value with it)")
     ap.add_argument("--rehearse-both", action="store_true",
                     help="run the N > 1 control flow (replicas, then Ulysses, both in the one JSON line) at world size 1")
     ap.add_argument("--selftest-launch", action="store_true",
@@ -838,43 +844,12 @@ def main():
         return {"elapsed": elapsed, "per_step": per_step, "sp": sp, "M": M, "ff1_ms": ff1_ms, "n_ff1": len(ff1),
                 "at_ms": at_ms, "n_at": len(at), "redo_items": int(redo.item())}
 
-    uly = uly3 = None
-    if ulysses_only:
-        runner.enable_ulysses()
-        r = measure(True)
-    else:
-        r = measure(False)
-        if (world > 1 or args.rehearse_both) and args.parallelism == "both":
-            # the replicas measurement above is the line's `value`; a failure of the Ulysses mode (it could only be run
-            # at world size 1 on hardware so far) must not take that number with it: it is reported instead
-            # (a failure inside a collective on one rank only still ends in the process group's timeout; what the flag
-            # agreed below covers is a rank that fails BETWEEN collectives -- allocation, a refused shape -- and would
-            # otherwise leave the others alone in the next leg)
-            err = None
-            try:
-                runner.enable_ulysses()
-                uly = measure(True)
-            except Exception as e:  # noqa: BLE001
-                err = f"{type(e).__name__}: {e}"[:400]
-            if agree_failed(err, dist, device):
-                uly = {"error": err or "another rank failed in the Ulysses leg"}
-            # BASELINE config 3, the workload the Ulysses mode is named for: 2B i2v 1216x704x121 = 16 x 22 x 38 = 13376
-            # tokens, first latent frame conditioned (per-token timesteps), one video over the ranks
-            if "error" not in uly:
-                err = None
-                try:
-                    runner.set_grid(GRID_CONFIG3, image_conditioned=True)
-                    uly3 = measure(True)
-                except Exception as e:  # noqa: BLE001
-                    err = f"{type(e).__name__}: {e}"[:400]
-                if agree_failed(err, dist, device):
-                    uly3 = {"error": err or "another rank failed in the Ulysses config-3 leg"}
-                runner.set_grid(GRID)
-            runner.sp = None
-    ms_per_step = r["elapsed"] / args.steps * 1e3
-    value = (1 if ulysses_only else world) * args.steps / r["elapsed"]
+    line = None
 
-    if rank == 0:
+    def build_line():
+        """rank 0: the line's headline part from the measurement r (everything the contract asks for)."""
+        ms_per_step = r["elapsed"] / args.steps * 1e3
+        value = (1 if ulysses_only else world) * args.steps / r["elapsed"]
         sp, M = r["sp"], r["M"]
         ff1_flop = 2.0 * M * FF * D
         ff1_tf = ff1_flop / (r["ff1_ms"] * 1e-3) / 1e12 if r["ff1_ms"] > 0 else 0.0
@@ -930,39 +905,106 @@ def main():
                               "launch_ms": round(r["ff1_ms"], 4), "launches_timed": r["n_ff1"],
                               "algorithmic_flop_per_launch": ff1_flop},
         }
-        if uly3 is not None:
-            n3 = GRID_CONFIG3[0] * GRID_CONFIG3[1] * GRID_CONFIG3[2]
-            if "error" in uly3:
-                line["ulysses_config3"] = {"error": uly3["error"]}
-            else:
-                line["ulysses_config3"] = {
-                    "workload": "LTX-Video 2B i2v 1216x704x121 (13376 tokens, first latent frame conditioned: per-token timesteps), "
-                                "B_eff 3, one video over the ranks", "tokens": n3, "parallelism": f"ulysses sp{world}",
-                    "value": round(args.steps / uly3["elapsed"], 4), "unit": "denoise-steps/s (ONE video)", "scaling": "strong",
-                    "ms_per_step": round(uly3["elapsed"] / args.steps * 1e3, 2),
-                    "step_ms": {"median": round(pct(uly3["per_step"], 0.5), 3), "p10": round(pct(uly3["per_step"], 0.1), 3),
-                                "p90": round(pct(uly3["per_step"], 0.9), 3)},
-                    "attention_launch_ms": round(uly3["at_ms"], 4)}
-        if uly is not None and "error" in uly:
+        return line
+
+    def put_ulysses(line, uly):
+        if "error" in uly:
             line["ulysses"] = {"error": uly["error"], "parallelism": f"ulysses sp{world}"}
-        elif uly is not None:
-            ums = uly["elapsed"] / args.steps * 1e3
-            line["ulysses"] = {"value": round(args.steps / uly["elapsed"], 4), "unit": "denoise-steps/s (ONE video)",
-                               "scaling": "strong", "ms_per_step": round(ums, 2), "parallelism": f"ulysses sp{world}",
-                               "step_ms": {"median": round(pct(uly["per_step"], 0.5), 3),
-                                           "p10": round(pct(uly["per_step"], 0.1), 3),
-                                           "p90": round(pct(uly["per_step"], 0.9), 3)},
-                               "attention_launch_ms": round(uly["at_ms"], 4),
-                               "note": "same step, tokens sharded N/P per rank, packed q,k,v all-to-all + o all-to-all per "
-                                       "layer over RCCL, final all-gather (ltxmi/distributed.py)"}
-    if (world > 1 or args.rehearse_both) and args.parallelism == "both" and not args.no_extras:
-        # the VAE half of the metric over the ranks (every rank takes part: collective)
-        try:
-            vtp = time_vae_tile_parallel(device, 3, dist)
-        except Exception as e:  # noqa: BLE001
-            vtp = {"error": f"{type(e).__name__}: {e}"[:400]}
+            return
+        ums = uly["elapsed"] / args.steps * 1e3
+        line["ulysses"] = {"value": round(args.steps / uly["elapsed"], 4), "unit": "denoise-steps/s (ONE video)",
+                           "scaling": "strong", "ms_per_step": round(ums, 2), "parallelism": f"ulysses sp{world}",
+                           "step_ms": {"median": round(pct(uly["per_step"], 0.5), 3),
+                                       "p10": round(pct(uly["per_step"], 0.1), 3),
+                                       "p90": round(pct(uly["per_step"], 0.9), 3)},
+                           "attention_launch_ms": round(uly["at_ms"], 4),
+                           "note": "same step, tokens sharded N/P per rank, packed q,k,v all-to-all + o all-to-all per "
+                                   "layer over RCCL, final all-gather (ltxmi/distributed.py)"}
+
+    def put_ulysses_config3(line, uly3):
+        n3 = GRID_CONFIG3[0] * GRID_CONFIG3[1] * GRID_CONFIG3[2]
+        if "error" in uly3:
+            line["ulysses_config3"] = {"error": uly3["error"]}
+            return
+        line["ulysses_config3"] = {
+            "workload": "LTX-Video 2B i2v 1216x704x121 (13376 tokens, first latent frame conditioned: per-token timesteps), "
+                        "B_eff 3, one video over the ranks", "tokens": n3, "parallelism": f"ulysses sp{world}",
+            "value": round(args.steps / uly3["elapsed"], 4), "unit": "denoise-steps/s (ONE video)", "scaling": "strong",
+            "ms_per_step": round(uly3["elapsed"] / args.steps * 1e3, 2),
+            "step_ms": {"median": round(pct(uly3["per_step"], 0.5), 3), "p10": round(pct(uly3["per_step"], 0.1), 3),
+                        "p90": round(pct(uly3["per_step"], 0.9), 3)},
+            "attention_launch_ms": round(uly3["at_ms"], 4)}
+
+    if ulysses_only:
+        runner.enable_ulysses()
+        r = measure(True)
         if rank == 0:
-            line["vae_decode_config5_tile_parallel"] = vtp
+            line = build_line()
+    else:
+        r = measure(False)
+        if rank == 0:
+            line = build_line()
+        if (world > 1 or args.rehearse_both) and args.parallelism == "both":
+            # The replicas measurement above is the line's `value`.  The legs below run collectives on paths that could only be
+            # run at world size 1 on hardware so far.  Two nets under them: an exception between collectives is agreed among
+            # the ranks and reported (agree_failed); a HANG inside a collective ends in the watchdog, which prints the line as it
+            # stands (rank 0 fills it leg by leg) with an error entry and ends this rank -- every rank runs its own, with the
+            # same deadline.
+            done = {"legs": []}
+
+            def expired():
+                msg = (f"watchdog: the collective legs did not finish within {args.collective_timeout:g} s "
+                       f"(finished: {done['legs'] or 'none'}); the replicas measurement is unaffected")
+                sys.stderr.write(f"[bench rank {rank}] {msg}\n")
+                sys.stderr.flush()
+                if rank == 0:
+                    for key in ("ulysses", "ulysses_config3", "vae_decode_config5_tile_parallel"):
+                        if key not in line and not (key.startswith("vae") and args.no_extras):
+                            line[key] = {"error": msg}
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+            watchdog = threading.Timer(args.collective_timeout, expired)
+            watchdog.daemon = True
+            watchdog.start()
+            err = None
+            try:
+                runner.enable_ulysses()
+                uly = measure(True)
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"[:400]
+            if agree_failed(err, dist, device):
+                uly = {"error": err or "another rank failed in the Ulysses leg"}
+            if rank == 0:
+                put_ulysses(line, uly)
+            done["legs"].append("ulysses")
+            # BASELINE config 3, the workload the Ulysses mode is named for: 2B i2v 1216x704x121 = 16 x 22 x 38 = 13376
+            # tokens, first latent frame conditioned (per-token timesteps), one video over the ranks
+            if "error" not in uly:
+                err = None
+                uly3 = None
+                try:
+                    runner.set_grid(GRID_CONFIG3, image_conditioned=True)
+                    uly3 = measure(True)
+                except Exception as e:  # noqa: BLE001
+                    err = f"{type(e).__name__}: {e}"[:400]
+                if agree_failed(err, dist, device):
+                    uly3 = {"error": err or "another rank failed in the Ulysses config-3 leg"}
+                runner.set_grid(GRID)
+                if rank == 0:
+                    put_ulysses_config3(line, uly3)
+                done["legs"].append("ulysses_config3")
+            runner.sp = None
+            if not args.no_extras:
+                # the VAE half of the metric over the ranks (every rank takes part: collective)
+                try:
+                    vtp = time_vae_tile_parallel(device, 3, dist)
+                except Exception as e:  # noqa: BLE001
+                    vtp = {"error": f"{type(e).__name__}: {e}"[:400]}
+                if rank == 0:
+                    line["vae_decode_config5_tile_parallel"] = vtp
+                done["legs"].append("vae_decode_config5_tile_parallel")
+            watchdog.cancel()
     extras = (not args.no_extras) and world == 1 and not ulysses_only
     if extras:
         # B_eff = 1 (report both): the same model, the text row only

@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -49,3 +51,23 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
                        timeout=300)
     assert r.returncode != 0 and _json_lines(r.stdout) == []
     assert "WORLD_SIZE=4" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_watchdog_prints_the_replicas_line_when_the_collective_legs_hang():
+    """The legs that run collectives (Ulysses, tile-parallel decode) have only ever run at world size 1 on hardware: a hang in
+    them must not cost the line its `value`.  With a deadline no leg can meet, the bench still prints ONE line -- the replicas
+    measurement with error entries for those legs -- and exits 0; with the default deadline the same command fills them in."""
+    cmd = [sys.executable, BENCH, "--steps", "2", "--warmup", "1", "--no-extras", "--rehearse-both"]
+    r = subprocess.run(cmd + ["--collective-timeout", "0.05"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = lines[0]
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert "watchdog" in line["ulysses"]["error"] and "watchdog" in line["ulysses_config3"]["error"]
+    assert "watchdog" in r.stderr
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_lines(r.stdout)[0]
+    assert line["ulysses"]["value"] > 0 and line["ulysses_config3"]["value"] > 0
