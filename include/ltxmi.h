@@ -20,7 +20,7 @@
  *   - argument structs (ltxmi_*_args) MUST be zero-initialised before the fields in use are
  *     set (`ltxmi_gemm_args a = {0};` / memset): versions append optional fields at the tail
  *     (0.2: rowsumsq*, a_kblock* of ltxmi_gemm_args; q_rowsumsq*, q_norm*, rope_*, o_segment*
- *     of ltxmi_attn_args; 0.3: q_rstd*; 0.4: conv3d post_*; 0.5: redo_counter, force_exact of ltxmi_attn_args, y_norm of ltxmi_conv3d_args), and a zero there means "off".  A caller must be
+ *     of ltxmi_attn_args; 0.3: q_rstd*; 0.4: conv3d post_*; 0.5: redo_counter, force_exact of ltxmi_attn_args, y_norm, workspace of ltxmi_conv3d_args), and a zero there means "off".  A caller must be
  *     rebuilt against the header of the library it loads.  An optional pointer that is NULL
  *     switches its companion size / stride fields off whatever they hold.
  */
@@ -288,6 +288,13 @@ typedef struct ltxmi_conv3d_args {
      * reads y back.  `add` with Cout == 128, or d2s with Cout == 1024 (post_scale / post_shift are [B, 128] then); ask
      * ltxmi_conv3d_fuses_post_norm(). */
     void* y_norm;
+    /* 0.5 (optional, NULL / 0 = off): scratch memory the call may use.  With at least ltxmi_conv3d_workspace_bytes(args) bytes
+     * (16-byte aligned) a wide, short layer (Cin >= 1024, Cout a multiple of 1024 up to 4096) whose tiles do not fill the chip runs
+     * split over its input channels: fp32 partial sums of 2 .. 4 channel ranges into the workspace, summed in range order by a
+     * finalising pass that applies the epilogue -- and post_norm / y_norm at ANY width (it holds whole rows).  Results are those of
+     * the unsplit call to fp32 summation order.  The contents are meaningless before and after the call; the same workspace may
+     * serve every call on a stream. */
+    void* workspace; int64_t workspace_bytes;
 } ltxmi_conv3d_args;
 
 /* Two implementations behind this entry, chosen by shape: a direct convolution with the input halo
@@ -299,6 +306,9 @@ int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* args, void* stream);
  * with Cout == 128, plain store, no `add`; with y_norm set: `add` and Cout == 128, or d2s and Cout == 1024), 0 otherwise.  Reads the fields that choose the implementation (shape, flags, algo,
  * bias != NULL); no launch. */
 int ltxmi_conv3d_fuses_post_norm(const ltxmi_conv3d_args* args);
+/* Bytes of workspace with which ltxmi_conv3d_ndhwc_bf16(args) would run split over its input channels (see
+ * ltxmi_conv3d_args.workspace); 0 when it would not.  Reads the shape, flags and algo; ignores args->workspace*. */
+int64_t ltxmi_conv3d_workspace_bytes(const ltxmi_conv3d_args* args);
 
 /* PixelNorm (pixel_norm.py:5-12, eps 1e-8) -> optional (1+scale)*x+shift per (batch, channel)
  * (ResnetBlock3D AdaLN, causal_video_autoencoder.py:1206-1243, Decoder tail :771-795)

@@ -91,6 +91,7 @@ int reserve_lds(const void* kernel, int bytes, unsigned long long* done, const c
 int device_cu_count(const char* what);
 // conv_direct.hip: direct 3x3x3 convolution; -1 = shape not taken (use the implicit GEMM)
 int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream);
+int64_t conv3d_direct_workspace_bytes(const ltxmi_conv3d_args* a);   // conv_direct.hip: the workspace a call would like (0: none)
 bool conv3d_direct_fuses_post_norm(const ltxmi_conv3d_args* a);     // conv_direct.hip: would this call apply post_norm in its epilogue
 
 }  // namespace ltxmi

@@ -27,6 +27,11 @@ struct ConvDirectP {
     int tiles_t, tiles_y, tiles_x, tiles_n;
     const float* post_scale; const float* post_shift; float post_eps;      // EPI >= 3 only
     uint16_t* y2;                                                          // EPI 4 / 5: the activated second output
+    // four-wave form only.  swap_hw: the tile's 16-position rows run along H and its 8 rows along W (W = 24 is 1.5 tiles of 16,
+    // H = 16 exactly one: 21 tiles instead of 28 at the 1024-channel stage).  ksplit > 1: the input channels are cut into ksplit
+    // ranges, one workgroup each (grid x ksplit), whose fp32 partial sums go to `part` [ksplit][B T H W][Cout] (EPI 6, no bias);
+    // conv_split_finalize_kernel adds them up and applies the epilogue
+    int swap_hw, ksplit; float* part;
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page_cd[16];
@@ -507,7 +512,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
     // the bf16 values of y -- the next ResnetBlock3D's norm1 -> AdaLN -> SiLU (causal_video_autoencoder.py:1197-1224), or the
     // decoder's tail (:771-795), without the launch that would read y back.  Needs all channels of an output position in one
     // wave: Cout == 128 (EPI 4), Cout == 8 * 128 (EPI 5: a 128-column block is one (p1 p2 p3)).
-    constexpr bool DUAL = (EPI >= 4);
+    constexpr bool PART = (EPI == 6);                                 // fp32 partial sums of a channel range (see ConvDirectP::ksplit)
+    constexpr bool DUAL = (EPI == 4 || EPI == 5);
     constexpr bool ADD = (EPI == 1 || EPI == 4), D2S = (EPI == 2 || EPI == 5), PNORM = (EPI == 3 || DUAL);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
@@ -519,9 +525,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
     const int nb = id % p.tiles_n; id /= p.tiles_n;
     const int tx = id % p.tiles_x; id /= p.tiles_x;
     const int ty = id % p.tiles_y; id /= p.tiles_y;
-    const int tt = id % p.tiles_t;
-    const int b = id / p.tiles_t;
-    const int t0 = tt * TT, y0 = ty * TY, x0 = tx * TX, n0 = nb * 128;
+    const int tt = id % p.tiles_t; id /= p.tiles_t;
+    const int b = id % p.B;
+    const int ks = id / p.B;                                          // channel range of this workgroup (0 unless ksplit > 1)
+    const int t0 = tt * TT, y0 = ty * TY, x0 = tx * TX, n0 = nb * 128;     // y0: the tile's 8-row direction, x0: its 16-position one
+    // tile coordinates -> image coordinates (swap_hw: the 16-position direction is H)
+    const bool swp = p.swap_hw != 0;
+    auto img_y = [&](int i8, int i16) __attribute__((always_inline)) { return swp ? x0 + i16 : y0 + i8; };
+    auto img_x = [&](int i8, int i16) __attribute__((always_inline)) { return swp ? y0 + i8 : x0 + i16; };
+    // this workgroup's input channels: chunks of 32, dealt as evenly as they go
+    const int nch_all = p.Cin >> 5, ch_base = nch_all / p.ksplit, ch_rem = nch_all - ch_base * p.ksplit;
+    const int c_first = (ks * ch_base + min(ks, ch_rem)) << 5;
+    const int nchunks = ch_base + (ks < ch_rem ? 1 : 0);
+    const int c_end = c_first + (nchunks << 5);
 
     // ---- row table (rows of zero padding, and the 12 rows that pad a plane to whole pieces: an offset past the descriptor)
     const int64_t x_bytes = (int64_t)p.B * p.T * p.H * p.W * p.Cin * 2;
@@ -533,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
         for (int r = tid; r < HALO_ROWS; r += 256) {
             const int ht = r / PLANE_STRIDE, rr = r - ht * PLANE_STRIDE;
             const int hy = rr / HX, hx = rr - hy * HX;
-            int ti = t0 + ht - p.tpad, yi = y0 + hy - 1, xi = x0 + hx - 1;
+            int ti = t0 + ht - p.tpad, yi = img_y(hy - 1, hx - 1), xi = img_x(hy - 1, hx - 1);
             const bool toob = (ti < 0) | (ti >= p.T);
             const bool oob = (yi < 0) | (yi >= p.H) | (xi < 0) | (xi >= p.W);
             ti = ti < 0 ? 0 : (ti >= p.T ? p.T - 1 : ti);
@@ -559,7 +575,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
         const int q = w + 4 * piece_slot(tap);
         const int hq = (win & (q >= lo) & (q < hi)) ? q : 0xff;
         const int tn = tap < 26 ? tap + 1 : 0;
-        const int n_off = (tn / 9) * PLANE_STRIDE + ((tn / 3) % 3) * HX + tn % 3;
+        // (the tap's dy runs along H, its dx along W: with swap_hw those are the halo's 16-position / 8-row directions)
+        const int n_off = (tn / 9) * PLANE_STRIDE + (swp ? (tn % 3) * HX + (tn / 3) % 3 : ((tn / 3) % 3) * HX + tn % 3);
         const int qn = w + 4 * piece_slot(tn);
         const int n_q = qn < 0 ? 0 : qn < Q_END ? qn : Q_END - 1;
         ctltab[tid * 2] = (uint32_t)(t2 * p.Cin * 2) | (wrap2 ? 0x80000000u : 0u);
@@ -580,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
     };
     auto unpack_ctl = [&](uint32_t d0, uint32_t d1, int c0) __attribute__((always_inline)) -> Ctl {
         Ctl k;
-        const int c_next = c0 + 32 < p.Cin ? c0 + 32 : -1;
+        const int c_next = c0 + 32 < c_end ? c0 + 32 : -1;
         const int c2 = (int)d0 < 0 ? c_next : c0;
         k.w_soff = c2 >= 0 ? (int)(d0 & 0x7fffffffu) + c2 * 2 : -1;
         k.n_off = (int)(d1 & 0x1ffu);
@@ -632,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
     };
-    int s_tap = 0, s_c0 = 0;
+    int s_tap = 0, s_c0 = c_first;
     Ctl cur;
     auto tap_body = [&](auto cur_tag, auto nxt_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(cur_tag)::value, N = decltype(nxt_tag)::value;
@@ -674,7 +691,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
     };
 
     // ---- in front of the stream: planes 0 and 1 of the first chunk's halo, the weights of its taps 0 and 1
-    const int nchunks = p.Cin >> 5;
     // Two workgroups share a CU and each SIMD has one wave of either.  With equal priorities the two waves of a SIMD drift into
     // phase (both in their MFMAs, at half rate each, then both in everything else with the pipe idle); a static priority for one of
     // them keeps them apart.  Workgroups are dealt to the CUs' first slots, then to their second slots, 256 at a time, so bit 8
@@ -685,10 +701,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
 #pragma unroll
     for (int k = 0; k < Q_PLANE1 / 4; ++k) {
         const int q = wave + 4 * k;
-        blds16(x_rsrc, halo + q * 1024, rowtab[q * 16 + (lane >> 2)] + hslot, 0);
+        blds16(x_rsrc, halo + q * 1024, rowtab[q * 16 + (lane >> 2)] + hslot, c_first * 2);
     }
-    load_w(0, 0);
-    load_w(1, p.Cin * 2);
+    load_w(0, c_first * 2);
+    load_w(1, (p.Cin + c_first) * 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
@@ -696,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
 #pragma unroll
     for (int j = 0; j < 8; ++j) bfr[j] = *(const bf16x8*)(wst + b_off0 + j * 1024);
     cur = unpack_ctl((uint32_t)__builtin_amdgcn_readfirstlane((int)ctltab[wave * 54]),
-                     (uint32_t)__builtin_amdgcn_readfirstlane((int)ctltab[wave * 54 + 1]), 0);
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)ctltab[wave * 54 + 1]), c_first);
     read_hoff(wave + 24);                                        // tap 0's piece slot: wave + 4 * 6
     read_ctl(1);
     {
@@ -716,6 +732,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
     // store instruction writes whole 128-byte rows.
     char* scr = smem + wave * 4096;
     const int ecol = (lane >> 4) * 4;
+    if (PART) {
+        // this channel range's fp32 sums, as they are (no bias): 16 bytes per lane and channel block, 64 contiguous bytes per position
+        float* dst = p.part + (int64_t)ks * p.B * p.T * p.H * p.W * p.Cout;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pos = wave * 64 + i * 16 + frow;
+            const int t = t0 + (pos >> 7), yy = img_y((pos >> 4) & 7, pos & 15), xx = img_x((pos >> 4) & 7, pos & 15);
+            if (t < p.T && yy < p.H && xx < p.W) {
+                float* row = dst + ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.Cout + n0 + ecol;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *(f32x4*)(row + j * 16) = acc[i][j];
+            }
+        }
+        return;
+    }
     const int Cp = D2S ? (p.Cout >> 3) : p.Cout, pp = D2S ? n0 / Cp : 0, cbase = n0 - pp * Cp;   // D2S: this block lies inside one (p1 p2 p3)
     // per-channel operands (the block's 128 bias values; EPI >= 3: 128 scales and shifts) go through a 1.25-KB table in the wave's
     // own LDS: one cooperative load, then 8- / 16-byte reads where they are used instead of registers held across the epilogue
@@ -729,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pos = wave * 64 + i * 16 + frow;
-        const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1), xx = min(x0 + (pos & 15), p.W - 1);
+        const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(img_y((pos >> 4) & 7, pos & 15), p.H - 1), xx = min(img_x((pos >> 4) & 7, pos & 15), p.W - 1);
         prow[i] = (((int64_t)b * p.T + t) * p.H + yy) * p.W + xx;
     }
     u32x4 add_v[2][2][4];                                                  // EPI 1: `add` in the stores' row-major layout
@@ -741,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
 #pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4) {
                     const int pos = wave * 64 + c * 32 + t4 * 8 + (lane >> 3);
-                    const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(y0 + ((pos >> 4) & 7), p.H - 1), xx = min(x0 + (pos & 15), p.W - 1);
+                    const int t = min(t0 + (pos >> 7), p.T - 1), yy = min(img_y((pos >> 4) & 7, pos & 15), p.H - 1), xx = min(img_x((pos >> 4) & 7, pos & 15), p.W - 1);
                     const int n = min(n0 + h * 64 + (lane & 7) * 8, p.Cout - 8);
                     add_v[h][c][t4] = *(const u32x4*)(p.add + ((((int64_t)b * p.T + t) * p.H + yy) * p.W + xx) * p.Cout + n);
                 }
@@ -854,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
                     const int row_l = t4 * 8 + (lane >> 3), chunk = lane & 7;
                     u32x4 w = *(const u32x4*)(scr + row_l * 128 + ((chunk ^ (row_l & 7)) << 4));
                     const int pos = wave * 64 + c * 32 + row_l;
-                    const int t = t0 + (pos >> 7), yy = y0 + ((pos >> 4) & 7), xx = x0 + (pos & 15);
+                    const int t = t0 + (pos >> 7), yy = img_y((pos >> 4) & 7, pos & 15), xx = img_x((pos >> 4) & 7, pos & 15);
                     if (D2S) {
                         // weight rows are packed (p1 p2 p3)-major: the 128 columns of this block are one pp
                         const int cp = cbase + h * 64 + chunk * 8;
@@ -880,6 +911,140 @@ __global__ __launch_bounds__(256, 2) void conv3d_direct_v3_kernel(ConvDirectP p)
 }
 }  // namespace v3
 
+// =====================================================================================================================
+// Split over the input channels (round 4).  At the 1024-channel stage of the decoder (4992 positions) a layer is 168-224 tiles:
+// one partial round of the chip whatever the kernel.  There the four-wave form cuts the input channels into ksplit ranges (three:
+// 504 workgroups for its 512 slots), every workgroup writes the fp32 sums of its range (EPI 6), and this kernel -- one workgroup
+// per output position of the convolution grid, a thread per CPT consecutive channels -- adds the ranges up IN RANGE ORDER, adds the
+// bias and applies the epilogue of the layer: plain store, + add, or the depth-to-space store (+ residual), each with the
+// optional PixelNorm -> (1 + scale) x + shift -> SiLU as the only or as a second output (a row of the partial sums holds every
+// channel of its position(s), so the norm rides here at any width).  The arithmetic of the values mirrors the fused epilogues:
+// y = bf16(sum + bias [+ residual]), `add` added to the rounded value and rounded again, the statistic from the bf16 values when
+// the raw result is kept and from the fp32 ones when only the activated result is (EPI 3's form).
+struct ConvFinalizeP {
+    const float* part; int ksplit; int64_t rows;             // [ksplit][rows][Cout]
+    const uint16_t* bias; const uint16_t* add; const uint16_t* res; int res_ch;
+    uint16_t* y; uint16_t* y2;                               // y2: the activated output (with y = NULL: the only one)
+    int B, T, H, W, Cout, d2s;
+    const float* post_scale; const float* post_shift; float post_eps; int post_norm;
+};
+
+template <int CPT>
+__global__ __launch_bounds__(256) void conv_split_finalize_kernel(ConvFinalizeP f) {
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = tid * CPT;
+    float v[CPT];
+    {
+        const float* src = f.part + row * f.Cout + c0;
+#pragma unroll
+        for (int q = 0; q < CPT / 4; ++q) {
+            const f32x4 a = *(const f32x4*)(src + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[q * 4 + e] = a[e];
+        }
+        for (int s = 1; s < f.ksplit; ++s) {
+            src += f.rows * f.Cout;
+#pragma unroll
+            for (int q = 0; q < CPT / 4; ++q) {
+                const f32x4 a = *(const f32x4*)(src + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[q * 4 + e] += a[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CPT / 4; ++q) {
+        const u32x2 bv = *(const u32x2*)(f.bias + c0 + q * 4);
+        v[q * 4 + 0] += bf_lo(bv[0]); v[q * 4 + 1] += bf_hi(bv[0]);
+        v[q * 4 + 2] += bf_lo(bv[1]); v[q * 4 + 3] += bf_hi(bv[1]);
+    }
+    const int Cp = f.d2s ? (f.Cout >> 3) : f.Cout;           // channels of an output position = the norm's width
+    const int pp = c0 / Cp, cp = c0 - pp * Cp;               // (CPT divides Cp: a thread's channels lie inside one (p1 p2 p3))
+    if (f.d2s && f.res) {
+        const uint32_t cmask = (uint32_t)(f.res_ch >> 3) - 1u;
+        const uint16_t* rrow = f.res + row * f.res_ch + pp;
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) {
+            asm volatile("" : "+v"(v[e]));                   // (conv + bias) + residual, in this order
+            v[e] += bf2f(rrow[(((uint32_t)(cp + e)) & cmask) << 3]);
+        }
+    }
+    const bool keep_raw = f.y != nullptr;
+    if (keep_raw) {
+        // the raw result as the fused epilogues round it
+#pragma unroll
+        for (int q = 0; q < CPT / 2; ++q) {
+            uint32_t r = pack_bf16(v[2 * q], v[2 * q + 1]);
+            if (f.add) {
+                const uint32_t a = *(const uint32_t*)(f.add + row * f.Cout + c0 + 2 * q);
+                r = pack_bf16(bf_lo(r) + bf_lo(a), bf_hi(r) + bf_hi(a));
+            }
+            v[2 * q] = bf_lo(r); v[2 * q + 1] = bf_hi(r);
+        }
+    }
+    float rstd = 0.f;
+    if (f.post_norm) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) s2 += v[e] * v[e];
+        const int tpg = Cp / CPT;                            // threads per norm group: a power of two, 32 .. 256
+        for (int off = 1; off < (tpg < 64 ? tpg : 64); off <<= 1) s2 += __shfl_xor(s2, off, 64);
+        if (tpg > 64) {
+            __shared__ float red[4];
+            if (lane == 0) red[wave] = s2;
+            __syncthreads();
+            const int gw = tpg >> 6, base = (wave / gw) * gw;
+            s2 = 0.f;
+            for (int k = 0; k < gw; ++k) s2 += red[base + k];
+        }
+        rstd = rsqrtf(s2 / (float)Cp + f.post_eps);
+    }
+    // where the position's channels go
+    int64_t out_off;
+    bool store = true;
+    if (f.d2s) {
+        int64_t r = row;
+        const int x_ = (int)(r % f.W); r /= f.W;
+        const int y_ = (int)(r % f.H); r /= f.H;
+        const int t_ = (int)(r % f.T);
+        const int b_ = (int)(r / f.T);
+        const int to = 2 * t_ + (pp >> 2) - 1, yo = 2 * y_ + ((pp >> 1) & 1), xo = 2 * x_ + (pp & 1);
+        store = to >= 0;                                     // the first upsampled frame is dropped
+        out_off = ((((int64_t)b_ * (2 * f.T - 1) + to) * (2 * f.H) + yo) * (2 * f.W) + xo) * Cp + cp;
+    } else {
+        out_off = row * f.Cout + c0;
+    }
+    if (!store) return;
+    if (keep_raw) {
+#pragma unroll
+        for (int q = 0; q < CPT / 4; ++q) {
+            u32x2 o;
+            o[0] = pack_bf16(v[4 * q], v[4 * q + 1]);
+            o[1] = pack_bf16(v[4 * q + 2], v[4 * q + 3]);
+            *(u32x2*)(f.y + out_off + 4 * q) = o;
+        }
+    }
+    if (f.post_norm) {
+        const int b_ = (int)(row / ((int64_t)f.T * f.H * f.W));
+#pragma unroll
+        for (int q = 0; q < CPT / 4; ++q) {
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (f.post_scale) {
+                sc = *(const f32x4*)(f.post_scale + (int64_t)b_ * Cp + cp + 4 * q);
+                sh = *(const f32x4*)(f.post_shift + (int64_t)b_ * Cp + cp + 4 * q);
+            }
+            float u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = silu_f(v[4 * q + e] * rstd * (1.0f + sc[e]) + sh[e]);
+            u32x2 o;
+            o[0] = pack_bf16(u[0], u[1]);
+            o[1] = pack_bf16(u[2], u[3]);
+            *(u32x2*)(f.y2 + out_off + 4 * q) = o;
+        }
+    }
+}
+
 }  // namespace ltxmi
 #ifdef LTXMI_CONV_STAMPS
 extern "C" int ltxmi_debug_set_conv_stamps(void* buf) {
@@ -901,19 +1066,72 @@ static bool conv3d_direct_takes(const ltxmi_conv3d_args* a) {
     if (a->d2s && a->residual && (a->res_channels < 8 || ((a->res_channels >> 3) & ((a->res_channels >> 3) - 1)) != 0)) return false;
     return true;
 }
-static int64_t conv3d_direct_grid(const ltxmi_conv3d_args* a) {
-    return (int64_t)a->B * ((a->T + CD_TT - 1) / CD_TT) * ((a->H + CD_TY - 1) / CD_TY) * ((a->W + CD_TX - 1) / CD_TX) * ((a->Cout + 127) / 128);
-}
 // whole 128-channel blocks: the four-wave form, two workgroups per CU (algo 3 asks for it, algo 4 for the eight-wave form)
 // (from 768 workgroups = 1.5 rounds of the chip's 512 slots; measured: 896 workgroups +5.8 %, 600 -0.6 %, 224 -21 %)
 static bool conv3d_direct_four_wave_form(const ltxmi_conv3d_args* a, int64_t grid) {
     return a->Cout % 128 == 0 && grid < (1ll << 31) && ((a->algo != 4 && grid >= 768) || a->algo == 3);
 }
+
+// How a call is laid out on the chip.  Tiles are 2 (t) x 8 x 16 positions; the 16-position direction is W, or H (swap: the
+// four-wave form only).  ksplit > 1: the input channels in ksplit ranges with fp32 partial sums and a finalising pass -- for the
+// wide, short layers (Cin >= 1024: the partial sums are Cin / (4 ksplit) times smaller than the halo traffic they replace) whose
+// tiles do not fill the chip: 1024 -> 1024 at 13 x 16 x 24 positions is 224 tiles of which 70 % of the positions exist (W = 24
+// is 1.5 tiles); swapped it is 168 tiles at 93 %, and three channel ranges make 504 workgroups for the 512 slots.
+struct ConvPlan {
+    bool four_wave; int swap, ksplit;
+    int tiles_t, tiles_8, tiles_16, tiles_n;      // tiles along t, the 8-row direction, the 16-position direction, 128-channel blocks
+    int64_t grid;                                 // workgroups of ONE channel range
+    int64_t workspace_bytes;                      // ksplit > 1: [ksplit][B T H W][Cout] fp32
+};
+static ConvPlan conv3d_direct_plan(const ltxmi_conv3d_args* a, bool have_workspace) {
+    ConvPlan pl;
+    pl.tiles_t = (a->T + CD_TT - 1) / CD_TT; pl.tiles_n = (a->Cout + 127) / 128;
+    const int64_t per = (int64_t)a->B * pl.tiles_t * pl.tiles_n;
+    const int64_t g_n = per * ((a->H + 7) / 8) * ((a->W + 15) / 16), g_s = per * ((a->W + 7) / 8) * ((a->H + 15) / 16);
+    pl.swap = 0; pl.ksplit = 1; pl.workspace_bytes = 0;
+    pl.four_wave = conv3d_direct_four_wave_form(a, g_n);
+    const double positions = (double)a->B * pl.tiles_t * CD_TT * a->H * a->W * pl.tiles_n;       // (x 128 channels each, t rounded up)
+    auto eff4 = [&](int64_t g, int S) {           // useful share of the tiles x fill of the last round of 512 slots - the split's price
+        const double rounds = (double)g * S / 512.0;
+        return positions / ((double)g * 256.0) * rounds / (double)(int64_t)(rounds + 0.999999) - 0.03 * (S - 1);
+    };
+    const double eff_now = pl.four_wave ? eff4(g_n, 1)
+                                        : positions / ((double)g_n * 256.0) * ((double)g_n / 256.0) / (double)((g_n + 255) / 256) * 0.93;
+    // the channel split: wide layers only, whole 1024-channel output rows for the finalising pass, the product's own choice
+    // (algo 0 / 2 / 3), and only where it buys more than 5 % of the launch
+    const int nch = a->Cin / 32;
+    if (a->Cout % 1024 == 0 && a->Cout <= 4096 && a->Cin >= 1024 && a->Cin % 32 == 0 && a->algo != 1 && a->algo != 4) {
+        const int64_t g = g_s < g_n ? g_s : g_n;
+        int best = 1;
+        double best_eff = eff_now + 0.05;
+        for (int S = 2; S <= 4 && S * 4 <= nch; ++S)
+            if (g * S < (1ll << 31) && eff4(g, S) > best_eff) { best = S; best_eff = eff4(g, S); }
+        if (best > 1) {
+            pl.workspace_bytes = (int64_t)best * a->B * a->T * a->H * a->W * a->Cout * 4;
+            if (have_workspace && a->workspace && a->workspace_bytes >= pl.workspace_bytes && (((uintptr_t)a->workspace) & 15) == 0) {
+                pl.ksplit = best; pl.four_wave = true; pl.swap = g_s < g_n;
+            }
+        }
+    }
+    if (pl.ksplit == 1 && pl.four_wave && (g_s + 511) / 512 < (g_n + 511) / 512) pl.swap = 1;    // fewer rounds of the chip
+    pl.tiles_8 = pl.swap ? (a->W + 7) / 8 : (a->H + 7) / 8;
+    pl.tiles_16 = pl.swap ? (a->H + 15) / 16 : (a->W + 15) / 16;
+    pl.grid = per * pl.tiles_8 * pl.tiles_16;
+    return pl;
+}
+int64_t conv3d_direct_workspace_bytes(const ltxmi_conv3d_args* a) {
+    if (a->algo == 1 || !conv3d_direct_takes(a)) return 0;
+    return conv3d_direct_plan(a, false).workspace_bytes;
+}
 // ltxmi_conv3d_fuses_post_norm: the four-wave form where a wave holds every channel of its output positions -- ONE 128-channel
 // block (plain store; with `add` only as the second output y_norm beside the raw y), or the depth-to-space store to 128 channels
-// (second output only: a 128-column block is one (p1 p2 p3))
+// (second output only: a 128-column block is one (p1 p2 p3)) -- and every call that runs split over its input channels (the
+// finalising pass holds whole rows)
 bool conv3d_direct_fuses_post_norm(const ltxmi_conv3d_args* a) {
-    if (a->algo == 1 || !conv3d_direct_takes(a) || !conv3d_direct_four_wave_form(a, conv3d_direct_grid(a))) return false;
+    if (a->algo == 1 || !conv3d_direct_takes(a)) return false;
+    const ConvPlan pl = conv3d_direct_plan(a, true);
+    if (pl.ksplit > 1) return true;
+    if (!pl.four_wave) return false;
     if (a->y_norm) return (a->d2s && a->Cout == 1024) || (!a->d2s && a->add && a->Cout == 128);
     return a->Cout == 128 && !a->d2s && !a->add;
 }
@@ -921,19 +1139,20 @@ bool conv3d_direct_fuses_post_norm(const ltxmi_conv3d_args* a) {
 // Returns -1 when the shape is not one this kernel takes (the caller then uses the implicit GEMM).
 int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
     if (!conv3d_direct_takes(a)) return -1;
+    const ConvPlan pl = conv3d_direct_plan(a, true);
     ConvDirectP p;
     p.x = (const uint16_t*)a->x; p.w = (const uint16_t*)a->w; p.bias = (const uint16_t*)a->bias;
     p.y = (uint16_t*)a->y; p.add = (const uint16_t*)a->add;
     p.res = a->d2s ? (const uint16_t*)a->residual : nullptr; p.res_ch = a->res_channels;
     p.B = a->B; p.T = a->T; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
     p.tpad = a->causal ? 2 : 1; p.pad_replicate = a->pad_replicate; p.tzero = a->time_pad_zeros ? 1 : 0;
-    p.tiles_t = (a->T + CD_TT - 1) / CD_TT; p.tiles_y = (a->H + CD_TY - 1) / CD_TY;
-    p.tiles_x = (a->W + CD_TX - 1) / CD_TX; p.tiles_n = (a->Cout + 127) / 128;
-    const int64_t grid = (int64_t)a->B * p.tiles_t * p.tiles_y * p.tiles_x * p.tiles_n;
+    p.tiles_t = pl.tiles_t; p.tiles_y = pl.tiles_8; p.tiles_x = pl.tiles_16; p.tiles_n = pl.tiles_n;
+    p.swap_hw = pl.swap; p.ksplit = pl.ksplit; p.part = (float*)a->workspace;
+    const int64_t grid = pl.grid * pl.ksplit;
     p.post_scale = a->post_scale; p.post_shift = a->post_shift; p.post_eps = a->post_eps;
     p.y2 = (uint16_t*)a->y_norm;
     if (a->post_norm && !conv3d_direct_fuses_post_norm(a)) return -1;
-    if (conv3d_direct_four_wave_form(a, grid)) {
+    if (pl.four_wave) {
 #define LTXMI_CDV3_LAUNCH(E)                                                                                   \
         {                                                                                                      \
             static unsigned long long lds_done = 0;                                                            \
@@ -942,6 +1161,26 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
                 return rc_;                                                                                    \
             hipLaunchKernelGGL(v3::conv3d_direct_v3_kernel<E>, dim3((unsigned)grid), dim3(256), v3::SMEM,      \
                                stream, p);                                                                     \
+        }
+        if (pl.ksplit > 1) {
+            LTXMI_CDV3_LAUNCH(6)
+            if (const int rc_ = check_launch("ltxmi_conv3d_ndhwc_bf16")) return rc_;
+            ConvFinalizeP f;
+            f.part = (const float*)a->workspace; f.ksplit = pl.ksplit; f.rows = (int64_t)a->B * a->T * a->H * a->W;
+            f.bias = p.bias; f.add = p.add; f.res = p.res; f.res_ch = p.res_ch;
+            // post_norm without y_norm: the activated result is the only output (to y); with y_norm: raw to y, activated to y_norm
+            f.y = (a->post_norm && !a->y_norm) ? nullptr : p.y;
+            f.y2 = a->post_norm ? (a->y_norm ? (uint16_t*)a->y_norm : p.y) : nullptr;
+            f.B = a->B; f.T = a->T; f.H = a->H; f.W = a->W; f.Cout = a->Cout; f.d2s = a->d2s;
+            f.post_scale = a->post_scale; f.post_shift = a->post_shift; f.post_eps = a->post_eps; f.post_norm = a->post_norm;
+            const dim3 fg((unsigned)f.rows);
+            switch (a->Cout / 256) {
+                case 4: hipLaunchKernelGGL(conv_split_finalize_kernel<4>, fg, dim3(256), 0, stream, f); break;
+                case 8: hipLaunchKernelGGL(conv_split_finalize_kernel<8>, fg, dim3(256), 0, stream, f); break;
+                case 12: hipLaunchKernelGGL(conv_split_finalize_kernel<12>, fg, dim3(256), 0, stream, f); break;
+                default: hipLaunchKernelGGL(conv_split_finalize_kernel<16>, fg, dim3(256), 0, stream, f); break;
+            }
+            return check_launch("ltxmi_conv3d_ndhwc_bf16");
         }
         if (a->d2s && a->post_norm) LTXMI_CDV3_LAUNCH(5)
         else if (a->add && a->post_norm) LTXMI_CDV3_LAUNCH(4)

@@ -1048,6 +1048,11 @@ extern "C" int ltxmi_conv3d_fuses_post_norm(const ltxmi_conv3d_args* a) {
                    conv3d_direct_fuses_post_norm(a) ? 1 : 0;
 }
 
+extern "C" int64_t ltxmi_conv3d_workspace_bytes(const ltxmi_conv3d_args* a) {
+    return a != nullptr && a->bias != nullptr && a->B > 0 && a->T > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0
+               ? conv3d_direct_workspace_bytes(a) : 0;
+}
+
 extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream) {
     LTXMI_REQUIRE(a && a->x && a->w && a->y, LTXMI_ERR_INVALID_ARG, "ltxmi_conv3d_ndhwc_bf16: NULL argument");
     LTXMI_REQUIRE(a->B > 0 && a->T > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0, LTXMI_ERR_INVALID_ARG,
@@ -1081,6 +1086,8 @@ extern "C" int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* a, void* stream)
     LTXMI_REQUIRE((((uintptr_t)a->x | (uintptr_t)a->w) & 15) == 0 && (((uintptr_t)a->y | (uintptr_t)a->bias) & 7) == 0,
                   LTXMI_ERR_UNSUPPORTED, "ltxmi_conv3d_ndhwc_bf16: misaligned pointer");
     LTXMI_REQUIRE(a->algo >= 0 && a->algo <= 4, LTXMI_ERR_INVALID_ARG, "ltxmi_conv3d_ndhwc_bf16: algo %d not in {0 .. 4}", a->algo);
+    LTXMI_REQUIRE(a->workspace_bytes >= 0 && (a->workspace != nullptr || a->workspace_bytes == 0), LTXMI_ERR_INVALID_ARG,
+                  "ltxmi_conv3d_ndhwc_bf16: workspace_bytes without a workspace");
     if (a->post_norm) {
         LTXMI_REQUIRE(a->post_norm == 1 && (a->post_scale != nullptr) == (a->post_shift != nullptr) && a->post_eps >= 0.f,
                       LTXMI_ERR_INVALID_ARG, "ltxmi_conv3d_ndhwc_bf16: post_norm must be 0 or 1, post_scale / post_shift both given or both NULL");

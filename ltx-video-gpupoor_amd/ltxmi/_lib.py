@@ -52,7 +52,7 @@ class Conv3dArgs(ctypes.Structure):
                 ("stride_t", c_int), ("stride_hw", c_int), ("tpad", c_int), ("out_T", c_int),
                 ("kernel_t", c_int), ("time_pad_zeros", c_int), ("algo", c_int),
                 ("post_norm", c_int), ("post_scale", c_void_p), ("post_shift", c_void_p), ("post_eps", c_float),
-                ("y_norm", c_void_p)]
+                ("y_norm", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 
 
 # name -> (restype, argtypes); mirrors include/ltxmi.h one to one
@@ -80,6 +80,7 @@ SIGNATURES = {
                                              c_void_p]),
     "ltxmi_conv3d_ndhwc_bf16": (c_int, [ctypes.POINTER(Conv3dArgs), c_void_p]),
     "ltxmi_conv3d_fuses_post_norm": (c_int, [ctypes.POINTER(Conv3dArgs)]),
+    "ltxmi_conv3d_workspace_bytes": (c_int64, [ctypes.POINTER(Conv3dArgs)]),
     "ltxmi_pixelnorm_ada_silu_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                               c_int, c_float, c_void_p]),
     "ltxmi_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

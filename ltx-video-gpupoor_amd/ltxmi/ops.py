@@ -380,6 +380,10 @@ CONV_POST_NORM_FUSE = True
 # conv3d(post_norm=..., keep_raw=True): the consumer's norm as a second output of the producing convolution where it can
 # (False: always the second launch; tools/vae_time.py --ab-second-output)
 CONV_SECOND_OUTPUT_FUSE = True
+# conv3d: give the library the workspace it asks for (ltxmi_conv3d_workspace_bytes), i.e. let the wide, short layers run split over
+# their input channels (False: never; tools/vae_time.py --ab-split)
+CONV_SPLIT = True
+_conv_workspace = {}
 
 
 def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, add=None, out=None,
@@ -428,6 +432,15 @@ def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, a
         if not add.is_contiguous() or add.shape != (B, oT, oH, oW, Cout):
             raise ValueError("ltxmi.conv3d: `add` must be a contiguous [B,T,H,W,Cout] tensor")
         a.add = add.data_ptr()
+    # scratch for the channel-split form of the wide, short layers (ltxmi_conv3d_args.workspace): one buffer per device, grown on
+    # demand, shared by every call (stream-ordered: the next call's writes follow this call's reads)
+    if CONV_SPLIT:
+        want = int(lib.ltxmi_conv3d_workspace_bytes(ctypes.byref(a)))
+        if want > 0:
+            ws = _conv_workspace.get(x.device)
+            if ws is None or ws.numel() < want:
+                ws = _conv_workspace[x.device] = torch.empty(want, dtype=torch.uint8, device=x.device)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     second_launch = None
     out_norm = None
     if keep_raw and post_norm is None:

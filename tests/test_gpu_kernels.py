@@ -1009,6 +1009,102 @@ def test_conv3d_second_activated_output(kind):
     assert _lib.lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), None) == -1
 
 
+@pytest.mark.parametrize("kind,grid", [("plain", (5, 16, 24)), ("add", (4, 20, 28)), ("post_norm", (5, 16, 24)),
+                                       ("add_second", (3, 16, 24)), ("d2s_res_second", (3, 16, 24)), ("d2s", (5, 10, 24))])
+def test_conv3d_channel_split(kind, grid, monkeypatch):
+    """ltxmi_conv3d_args.workspace (0.5): the wide, short layers of the decoder's 1024-channel stage split over their input
+    channels (fp32 partial sums of 2 .. 4 ranges + a finalising pass that applies the epilogue, the norm at full width included),
+    on tiles whose 16-position rows run along H.  Against the same call without a workspace (the unsplit kernels: equal up to the
+    fp32 summation order, i.e. a bf16 ulp here and there) and against the fp32 oracle convolution; partial tiles on both axes."""
+    import ctypes
+    from ltxmi import ops, _lib
+    from oracle import vae as ov
+    B, (T, H, W), cin = 2 if kind == "post_norm" else 1, grid, 1024
+    d2s = kind.startswith("d2s")
+    cout = 2048 if d2s else 1024
+    c_norm = cout // 8 if d2s else cout
+    x = rnd(B, cin, T, H, W, seed=140)
+    w = rnd(cout, cin, 3, 3, 3, seed=141, scale=(27 * cin) ** -0.5)
+    b = rnd(cout, seed=142)
+    xd, bd = ndhwc(x).to(DEV), b.to(DEV)
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1)
+    if d2s:                                        # rows re-ordered (p1 p2 p3, c'): CausalConv3d.packed(d2s=True)
+        wp, bdd = wp.view(cout // 8, 8, -1).transpose(0, 1).reshape(cout, -1), b.view(cout // 8, 8).t().reshape(cout).to(DEV)
+    else:
+        bdd = bd
+    wp = wp.contiguous().to(DEV)
+    add = ndhwc(rnd(B, cout, T, H, W, seed=143)).to(DEV) if kind.startswith("add") else None
+    res = xd if kind.startswith("d2s_res") else None
+    pn = None
+    if "second" in kind or kind == "post_norm":
+        pn = (rnd(B, c_norm, seed=144, scale=0.3).float().to(DEV), rnd(B, c_norm, seed=145, scale=0.3).float().to(DEV), 1e-8)
+    keep = "second" in kind
+    a = _lib.Conv3dArgs()
+    a.bias, a.B, a.T, a.H, a.W, a.Cin, a.Cout, a.causal, a.pad_replicate, a.d2s = bdd.data_ptr(), B, T, H, W, cin, cout, 1, 1, int(d2s)
+    want = _lib.lib.ltxmi_conv3d_workspace_bytes(ctypes.byref(a))
+    assert want >= 2 * B * T * H * W * cout * 4 and want % (B * T * H * W * cout * 4) == 0, want
+
+    def run():
+        return ops.conv3d(xd, wp, bdd, True, True, d2s=d2s, residual=res, add=add, post_norm=pn, keep_raw=keep)
+
+    split = run()
+    monkeypatch.setattr(ops, "CONV_SPLIT", False)
+    plain = run()
+    torch.cuda.synchronize()
+    outs = list(zip(split, plain)) if keep else [(split, plain)]
+    for sp_, pl_ in outs:
+        assert sp_.shape == pl_.shape
+        d = (sp_.float() - pl_.float()).abs()
+        tol = pl_.float().abs() * 2.0 ** -6 + 2e-2           # two bf16 ulps of the value (summation order, then the norm's factor)
+        assert bool((d <= tol).all()), f"{kind}: split vs unsplit off by {float((d - tol).max()):.3e} beyond two bf16 ulps"
+        # (two bf16 renderings of the same tensor: the unsplit call of these small grids is the implicit GEMM, which adds `add`
+        # before its one rounding, and at this width its norm is a second launch on the rounded result)
+        assert float((sp_.float() - pl_.float()).norm() / pl_.float().norm()) < 6e-3
+    # the raw result against the fp32 oracle (post_norm-only: the activated one)
+    y = ov.causal_conv3d(x.float(), {"conv.weight": w.float(), "conv.bias": b.float()}, "", True, "replicate")
+    if d2s:
+        yt = ov.depth_to_space_upsample(x.float(), {"conv.conv.weight": w.float(), "conv.conv.bias": b.float()}, "",
+                                        dict(stride=(2, 2, 2), residual=res is not None, reduction=4), True, "replicate")
+        check(ncdhw((split[0] if keep else split).cpu()), yt, what=f"split {kind} vs oracle")
+    elif kind == "post_norm":
+        n = y * torch.rsqrt(y.pow(2).mean(dim=1, keepdim=True) + 1e-8)
+        n = n * (1 + pn[0].cpu()[:, :, None, None, None]) + pn[1].cpu()[:, :, None, None, None]
+        check(ncdhw(split.cpu()), torch.nn.functional.silu(n), what="split post_norm vs oracle")
+    else:
+        yt = y + (ncdhw(add.cpu()).float() if add is not None else 0)
+        check(ncdhw((split[0] if keep else split).cpu()), yt, what=f"split {kind} vs oracle")
+    # without a workspace the entry runs the unsplit kernels and refuses the norm at this width
+    a.x, a.w, a.y, a.post_norm, a.post_eps = xd.data_ptr(), wp.data_ptr(), (plain[0] if keep else plain).data_ptr(), 1, 1e-8
+    assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 0
+    ws = torch.empty(want, dtype=torch.uint8, device=DEV)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), want
+    assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 1
+    a.workspace_bytes = want - 16                            # too small: not used
+    assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 0
+
+
+def test_conv3d_tiles_with_their_rows_along_h():
+    """The four-wave direct convolution lays its 2 x 8 x 16 tiles with the 16-position rows along H where that takes fewer rounds of
+    the chip (W = 24: 1.5 tiles of 16; H = 16: exactly one).  Against the oracle, and against the same problem transposed in
+    (H, W) with transposed taps, which runs the ordinary layout (equal up to the order in which the taps are summed)."""
+    from ltxmi import ops
+    from oracle import vae as ov
+    B, T, H, W, cin, cout = 3, 100, 16, 24, 64, 128              # 600 tiles (2 rounds) the ordinary way, 450 (1 round) with rows along H
+    x = rnd(B, cin, T, H, W, seed=150)
+    w = rnd(cout, cin, 3, 3, 3, seed=151, scale=(27 * cin) ** -0.5)
+    b = rnd(cout, seed=152)
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous().to(DEV)
+    out = ops.conv3d(ndhwc(x).to(DEV), wp, b.to(DEV), True, False, algo=3)
+    truth = ov.causal_conv3d(x.float(), {"conv.weight": w.float(), "conv.bias": b.float()}, "", True, "zeros")
+    check(ncdhw(out.cpu()), truth, what="tiles with rows along H vs oracle")
+    xt, wt = x.transpose(3, 4).contiguous(), w.transpose(3, 4).contiguous()      # H <-> W: 24 x 16, ordinary layout (3 x 1 tiles)
+    wpt = wt.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous().to(DEV)
+    out_t = ops.conv3d(ndhwc(xt).to(DEV), wpt, b.to(DEV), True, False, algo=3).transpose(2, 3)
+    d = (out_t.float() - out.float()).abs()
+    assert bool((d <= out.float().abs() * 2.0 ** -7 + 1e-2).all()), float(d.max())
+    assert float((out_t.float() - out.float()).norm() / out.float().norm()) < 1e-3
+
+
 @pytest.mark.parametrize("cin,residual,red", [(256, True, 2), (128, False, 1)])
 @pytest.mark.parametrize("algo", [4, 3])
 def test_conv3d_direct_path_depth_to_space(cin, residual, red, algo, monkeypatch):

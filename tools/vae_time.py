@@ -4,7 +4,8 @@
     python tools/vae_time.py --ab-post-norm [rounds]    in-process A/B: conv1's norm2 -> SiLU in the convolution's epilogue
                                                         (ops.CONV_POST_NORM_FUSE) against the second launch, alternating decodes
     python tools/vae_time.py --ab-second-output [rounds]   the same for the consumer's norm as a second output of conv2 + skip / of
-                                                        the depth-to-space store (ops.CONV_SECOND_OUTPUT_FUSE)"""
+                                                        the depth-to-space store (ops.CONV_SECOND_OUTPUT_FUSE)
+    python tools/vae_time.py --ab-split [rounds]           the 1024-channel stage split over its input channels (ops.CONV_SPLIT)"""
 import os
 import sys
 
@@ -13,8 +14,8 @@ for p in (ROOT, os.path.join(ROOT, "ltx-video-gpupoor_amd")):
     sys.path.insert(0, p)
 import bench  # noqa: E402
 
-if len(sys.argv) > 1 and sys.argv[1] in ("--ab-post-norm", "--ab-second-output"):
-    knob = "CONV_POST_NORM_FUSE" if sys.argv[1] == "--ab-post-norm" else "CONV_SECOND_OUTPUT_FUSE"
+if len(sys.argv) > 1 and sys.argv[1] in ("--ab-post-norm", "--ab-second-output", "--ab-split"):
+    knob = {"--ab-post-norm": "CONV_POST_NORM_FUSE", "--ab-second-output": "CONV_SECOND_OUTPUT_FUSE", "--ab-split": "CONV_SPLIT"}[sys.argv[1]]
     import torch
     import ltxmi
     from ltxmi import ops
