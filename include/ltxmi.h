@@ -289,7 +289,7 @@ typedef struct ltxmi_conv3d_args {
      * ltxmi_conv3d_fuses_post_norm(). */
     void* y_norm;
     /* 0.5 (optional, NULL / 0 = off): scratch memory the call may use.  With at least ltxmi_conv3d_workspace_bytes(args) bytes
-     * (16-byte aligned) a wide, short layer (Cin >= 1024, Cout a multiple of 1024 up to 4096) whose tiles do not fill the chip runs
+     * (16-byte aligned) a wide, short layer (Cin >= 1024, or >= 512 with post_norm; Cout 512 or a multiple of 1024 up to 4096) whose tiles do not fill the chip runs
      * split over its input channels: fp32 partial sums of 2 .. 4 channel ranges into the workspace, summed in range order by a
      * finalising pass that applies the epilogue -- and post_norm / y_norm at ANY width (it holds whole rows).  Results are those of
      * the unsplit call to fp32 summation order.  The contents are meaningless before and after the call; the same workspace may
@@ -307,7 +307,8 @@ int ltxmi_conv3d_ndhwc_bf16(const ltxmi_conv3d_args* args, void* stream);
  * bias != NULL); no launch. */
 int ltxmi_conv3d_fuses_post_norm(const ltxmi_conv3d_args* args);
 /* Bytes of workspace with which ltxmi_conv3d_ndhwc_bf16(args) would run split over its input channels (see
- * ltxmi_conv3d_args.workspace); 0 when it would not.  Reads the shape, flags and algo; ignores args->workspace*. */
+ * ltxmi_conv3d_args.workspace); 0 when it would not.  Reads the shape, flags, algo and post_norm (at 512 input channels the split
+ * pays only when the finalising pass takes a norm along); ignores args->workspace*. */
 int64_t ltxmi_conv3d_workspace_bytes(const ltxmi_conv3d_args* args);
 
 /* PixelNorm (pixel_norm.py:5-12, eps 1e-8) -> optional (1+scale)*x+shift per (batch, channel)

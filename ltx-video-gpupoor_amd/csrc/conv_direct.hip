@@ -929,8 +929,8 @@ struct ConvFinalizeP {
     const float* post_scale; const float* post_shift; float post_eps; int post_norm;
 };
 
-template <int CPT>
-__global__ __launch_bounds__(256) void conv_split_finalize_kernel(ConvFinalizeP f) {
+template <int CPT, int NT = 256>       // NT threads x CPT channels = Cout
+__global__ __launch_bounds__(NT) void conv_split_finalize_kernel(ConvFinalizeP f) {
     const int64_t row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = tid * CPT;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void conv_split_finalize_kernel(ConvFinalizeP 
         const int tpg = Cp / CPT;                            // threads per norm group: a power of two, 32 .. 256
         for (int off = 1; off < (tpg < 64 ? tpg : 64); off <<= 1) s2 += __shfl_xor(s2, off, 64);
         if (tpg > 64) {
-            __shared__ float red[4];
+            __shared__ float red[NT / 64];
             if (lane == 0) red[wave] = s2;
             __syncthreads();
             const int gw = tpg >> 6, base = (wave / gw) * gw;
@@ -1097,15 +1097,24 @@ static ConvPlan conv3d_direct_plan(const ltxmi_conv3d_args* a, bool have_workspa
     };
     const double eff_now = pl.four_wave ? eff4(g_n, 1)
                                         : positions / ((double)g_n * 256.0) * ((double)g_n / 256.0) / (double)((g_n + 255) / 256) * 0.93;
-    // the channel split: wide layers only, whole 1024-channel output rows for the finalising pass, the product's own choice
-    // (algo 0 / 2 / 3), and only where it buys more than 5 % of the launch
+    // The channel split: the product's own choice (algo 0 / 2 / 3), output rows the finalising pass takes (512 or n x 1024
+    // channels).  Cin >= 1024: wherever it buys more than 5 % of the launch at 3 % per extra range.  512 <= Cin < 1024 (the partial
+    // sums cost twice as much per FLOP): two ranges only, and only for a call that asks for a norm the unsplit form could not
+    // fuse -- the finalising pass replaces that launch (0.084 ms beside a 0.55-ms convolution at the decoder's 512-channel stage,
+    // whose 624 workgroups are 2.44 rounds of the eight-wave form), which the efficiency figure does not see.
     const int nch = a->Cin / 32;
-    if (a->Cout % 1024 == 0 && a->Cout <= 4096 && a->Cin >= 1024 && a->Cin % 32 == 0 && a->algo != 1 && a->algo != 4) {
+    const bool rows_ok = (a->Cout == 512 || a->Cout % 1024 == 0) && a->Cout <= 4096;
+    const bool wants_unfusable_norm = a->post_norm && !(a->Cout == 128 || (a->d2s && a->Cout == 1024));
+    if (rows_ok && a->Cin % 32 == 0 && a->algo != 1 && a->algo != 4 && (a->Cin >= 1024 || (a->Cin >= 512 && wants_unfusable_norm))) {
         const int64_t g = g_s < g_n ? g_s : g_n;
+        const bool wide = a->Cin >= 1024;
+        const double price = wide ? 0.03 : 0.06;
         int best = 1;
-        double best_eff = eff_now + 0.05;
-        for (int S = 2; S <= 4 && S * 4 <= nch; ++S)
-            if (g * S < (1ll << 31) && eff4(g, S) > best_eff) { best = S; best_eff = eff4(g, S); }
+        double best_eff = wide ? eff_now + 0.05 : eff_now - 0.05;
+        for (int S = 2; S <= (wide ? 4 : 2) && S * 4 <= nch; ++S) {
+            const double e = eff4(g, S) + 0.03 * (S - 1) - price * (S - 1);
+            if (g * S < (1ll << 31) && e > best_eff) { best = S; best_eff = e; }
+        }
         if (best > 1) {
             pl.workspace_bytes = (int64_t)best * a->B * a->T * a->H * a->W * a->Cout * 4;
             if (have_workspace && a->workspace && a->workspace_bytes >= pl.workspace_bytes && (((uintptr_t)a->workspace) & 15) == 0) {
@@ -1175,6 +1184,7 @@ int launch_conv3d_direct(const ltxmi_conv3d_args* a, hipStream_t stream) {
             f.post_scale = a->post_scale; f.post_shift = a->post_shift; f.post_eps = a->post_eps; f.post_norm = a->post_norm;
             const dim3 fg((unsigned)f.rows);
             switch (a->Cout / 256) {
+                case 2: hipLaunchKernelGGL((conv_split_finalize_kernel<4, 128>), fg, dim3(128), 0, stream, f); break;
                 case 4: hipLaunchKernelGGL(conv_split_finalize_kernel<4>, fg, dim3(256), 0, stream, f); break;
                 case 8: hipLaunchKernelGGL(conv_split_finalize_kernel<8>, fg, dim3(256), 0, stream, f); break;
                 case 12: hipLaunchKernelGGL(conv_split_finalize_kernel<12>, fg, dim3(256), 0, stream, f); break;

@@ -1010,7 +1010,8 @@ def test_conv3d_second_activated_output(kind):
 
 
 @pytest.mark.parametrize("kind,grid", [("plain", (5, 16, 24)), ("add", (4, 20, 28)), ("post_norm", (5, 16, 24)),
-                                       ("add_second", (3, 16, 24)), ("d2s_res_second", (3, 16, 24)), ("d2s", (5, 10, 24))])
+                                       ("add_second", (3, 16, 24)), ("d2s_res_second", (3, 16, 24)), ("d2s", (5, 10, 24)),
+                                       ("post_norm_512", (9, 32, 48)), ("add_second_512", (9, 30, 44))])
 def test_conv3d_channel_split(kind, grid, monkeypatch):
     """ltxmi_conv3d_args.workspace (0.5): the wide, short layers of the decoder's 1024-channel stage split over their input
     channels (fp32 partial sums of 2 .. 4 ranges + a finalising pass that applies the epilogue, the norm at full width included),
@@ -1019,9 +1020,12 @@ def test_conv3d_channel_split(kind, grid, monkeypatch):
     import ctypes
     from ltxmi import ops, _lib
     from oracle import vae as ov
-    B, (T, H, W), cin = 2 if kind == "post_norm" else 1, grid, 1024
+    # (..._512: the decoder's 512-channel stage, split in two only because the norm rides on the finalising pass)
+    narrow = kind.endswith("_512")
+    kind = kind.replace("_512", "")
+    B, (T, H, W), cin = 2 if kind == "post_norm" else 1, grid, 512 if narrow else 1024
     d2s = kind.startswith("d2s")
-    cout = 2048 if d2s else 1024
+    cout = 2048 if d2s else cin
     c_norm = cout // 8 if d2s else cout
     x = rnd(B, cin, T, H, W, seed=140)
     w = rnd(cout, cin, 3, 3, 3, seed=141, scale=(27 * cin) ** -0.5)
@@ -1041,8 +1045,12 @@ def test_conv3d_channel_split(kind, grid, monkeypatch):
     keep = "second" in kind
     a = _lib.Conv3dArgs()
     a.bias, a.B, a.T, a.H, a.W, a.Cin, a.Cout, a.causal, a.pad_replicate, a.d2s = bdd.data_ptr(), B, T, H, W, cin, cout, 1, 1, int(d2s)
+    if narrow:
+        assert _lib.lib.ltxmi_conv3d_workspace_bytes(ctypes.byref(a)) == 0        # not without a norm to take along
+        a.post_norm = 1
     want = _lib.lib.ltxmi_conv3d_workspace_bytes(ctypes.byref(a))
     assert want >= 2 * B * T * H * W * cout * 4 and want % (B * T * H * W * cout * 4) == 0, want
+    a.post_norm = 0
 
     def run():
         return ops.conv3d(xd, wp, bdd, True, True, d2s=d2s, residual=res, add=add, post_norm=pn, keep_raw=keep)
