@@ -488,7 +488,10 @@ __global__ __launch_bounds__(512) void conv3d_direct_kernel(ConvDirectP p) {
 //                  128 rows x 64 B = 24 KB; row table 3 KB; control table 0.9 KB  => 75.8 KB per workgroup.  64-byte rows:
 //                  16-byte slot s of row r holds source chunk s ^ 2 ((r >> 2) & 1), conflict-free for the 16-lane groups of
 //                  ds_read_b128 at every row alignment (exhaustive search over the swizzles of that form)
-// The stream, the tables and the epilogues are the kernel above with these constants.
+// The stream and the tables are the kernel above with these constants.  Round 4 added, here only: one epilogue code path for
+// seven forms (0 plain, 1 + add, 2 depth-to-space + residual, 3 PixelNorm -> AdaLN -> SiLU of the result, 4 / 5 = 1 / 2 with that
+// as a SECOND output, 6 fp32 partial sums of a range of input channels), tiles whose 16-position rows run along H instead of W,
+// and the split over the input channels (ConvDirectP::swap_hw / ksplit, conv3d_direct_plan, conv_split_finalize_kernel below).
 namespace v3 {
 constexpr int TT = 2, TY = 8, TX = 16;
 constexpr int HT = TT + 2, HY = TY + 2, HX = TX + 2;
