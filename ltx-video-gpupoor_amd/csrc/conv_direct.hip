@@ -1141,6 +1141,7 @@ int64_t conv3d_direct_workspace_bytes(const ltxmi_conv3d_args* a) {
 // finalising pass holds whole rows)
 bool conv3d_direct_fuses_post_norm(const ltxmi_conv3d_args* a) {
     if (a->algo == 1 || !conv3d_direct_takes(a)) return false;
+    if (!a->y_norm && (a->add || a->d2s)) return false;      // the activated result as the ONLY output: the plain store only
     const ConvPlan pl = conv3d_direct_plan(a, true);
     if (pl.ksplit > 1) return true;
     if (!pl.four_wave) return false;

@@ -1089,6 +1089,13 @@ def test_conv3d_channel_split(kind, grid, monkeypatch):
     assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 1
     a.workspace_bytes = want - 16                            # too small: not used
     assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 0
+    # the activated result as the ONLY output is for the plain store: with `add` / depth-to-space it needs y_norm
+    a.workspace_bytes = want
+    if add is not None or d2s:
+        a.add = add.data_ptr() if add is not None else None
+        a.y_norm = None
+        assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 0
+        assert _lib.lib.ltxmi_conv3d_ndhwc_bf16(ctypes.byref(a), None) == -2 and b"post_norm" in _lib.lib.ltxmi_last_error()
 
 
 def test_conv3d_tiles_with_their_rows_along_h():
