@@ -1083,6 +1083,8 @@ def test_conv3d_channel_split(kind, grid, monkeypatch):
         check(ncdhw((split[0] if keep else split).cpu()), yt, what=f"split {kind} vs oracle")
     # without a workspace the entry runs the unsplit kernels and refuses the norm at this width
     a.x, a.w, a.y, a.post_norm, a.post_eps = xd.data_ptr(), wp.data_ptr(), (plain[0] if keep else plain).data_ptr(), 1, 1e-8
+    if d2s:
+        a.y_norm = plain[1].data_ptr() if keep else xd.data_ptr()      # (the queries launch nothing)
     assert _lib.lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)) == 0
     ws = torch.empty(want, dtype=torch.uint8, device=DEV)
     a.workspace, a.workspace_bytes = ws.data_ptr(), want
