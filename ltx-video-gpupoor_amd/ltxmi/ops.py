@@ -450,14 +450,15 @@ def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, a
             out_norm = torch.empty_like(out)
             a.y_norm = out_norm.data_ptr()
     # (after the norm request is in the arguments: at 512 input channels the split is only worth it when the norm rides along)
-    # Scratch for the channel-split form of the wide, short layers (ltxmi_conv3d_args.workspace): one buffer per device, grown on
-    # demand, shared by every call (stream-ordered: the next call's writes follow this call's reads)
+    # Scratch for the channel-split form of the wide, short layers (ltxmi_conv3d_args.workspace): one buffer per (device, stream),
+    # grown on demand, shared by every call on that stream (stream-ordered: the next call's writes follow this call's reads)
     if CONV_SPLIT:
         want = int(lib.ltxmi_conv3d_workspace_bytes(ctypes.byref(a)))
         if want > 0:
-            ws = _conv_workspace.get(x.device)
+            key = (x.device, torch.cuda.current_stream().cuda_stream)
+            ws = _conv_workspace.get(key)
             if ws is None or ws.numel() < want:
-                ws = _conv_workspace[x.device] = torch.empty(want, dtype=torch.uint8, device=x.device)
+                ws = _conv_workspace[key] = torch.empty(want, dtype=torch.uint8, device=x.device)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     if post_norm is not None:
         if not (CONV_SECOND_OUTPUT_FUSE if keep_raw else CONV_POST_NORM_FUSE) or not lib.ltxmi_conv3d_fuses_post_norm(ctypes.byref(a)):
