@@ -481,6 +481,30 @@ def test_vae_decode_through_direct_convolution():
     assert_parity(out, truth, eager, "vae decode through the direct convolution")
 
 
+@pytest.mark.parametrize("knobs", [(False, False, False), (True, False, False), (True, True, False), (True, True, True)])
+def test_vae_decode_with_the_epilogue_fusions_switched_off(knobs, monkeypatch):
+    """The decoder hands every PixelNorm -> AdaLN -> SiLU to the producer of its input; what the producer does with it is three
+    switches in ltxmi.ops (norm2 in conv1's epilogue, the consumer's norm as a second output, the channel split of the wide
+    stages with its finalising pass) and, for a C caller, the optional fields y_norm / workspace.  Every combination -- down to
+    every norm as a launch of its own, which is what a caller that passes none of the optional fields gets -- must render the
+    same video within the parity bound of the fp32 oracle, at the full-width decoder's channel counts."""
+    from oracle import vae as ov
+    from ltxmi import ops
+    import ltxmi
+    cfg, sd = vae_case("b", base=128)
+    z = torch.randn(1, 128, 3, 6, 8, generator=torch.Generator().manual_seed(19)).to(BF)
+    ts = torch.tensor([0.05])
+    truth = ov.vae_decode(sd, cfg, z.float(), ts)
+    sdb = {k: (v.to(BF) if v.is_floating_point() and v.dim() > 0 else v) for k, v in sd.items()}
+    eager = ov.vae_decode(sdb, cfg, z, ts)
+    v = build_vae(cfg, sd)
+    monkeypatch.setattr(ops, "CONV_POST_NORM_FUSE", knobs[0])
+    monkeypatch.setattr(ops, "CONV_SECOND_OUTPUT_FUSE", knobs[1])
+    monkeypatch.setattr(ops, "CONV_SPLIT", knobs[2])
+    out = ltxmi.vae_decode(z.to(DEV), v, True, vae_per_channel_normalize=True, timestep=ts.to(DEV))
+    assert_parity(out, truth, eager, f"vae decode, base 128, fusions {knobs}")
+
+
 def test_vae_decode_full_width():
     """The decoder the bench times: decoder_base_channels = 128 (1024 / 512 / 256 / 128 channels per stage, the
     d2s 1024 -> 4096 upsampler), on a latent the CPU oracle can decode in seconds."""
