@@ -458,6 +458,8 @@ def conv3d(x, w_packed, bias, causal, pad_replicate, d2s=False, residual=None, a
             key = (x.device, torch.cuda.current_stream().cuda_stream)
             ws = _conv_workspace.get(key)
             if ws is None or ws.numel() < want:
+                if ws is None and len(_conv_workspace) >= 8:          # streams come and go: do not keep their buffers for ever
+                    _conv_workspace.clear()
                 ws = _conv_workspace[key] = torch.empty(want, dtype=torch.uint8, device=x.device)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     if post_norm is not None:
