@@ -196,6 +196,37 @@ int main() {
     expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(post_norm on the implicit GEMM)", LTXMI_ERR_UNSUPPORTED);
     c.algo = 0; c.add = p;
     expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(post_norm with add)", LTXMI_ERR_UNSUPPORTED);
+    // y_norm (0.5): the norm as a SECOND output rides on conv2 + skip at Cout 128; y_norm needs post_norm and must not be y
+    c.y_norm = pf;
+    if (ltxmi_conv3d_fuses_post_norm(&c) != 1) { fprintf(stderr, "FAIL fuses_post_norm(add + y_norm, Cout 128)\n"); ++g_bad; }
+    expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(add + y_norm, no device)");
+    c.y_norm = c.y;
+    expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(y_norm == y)", LTXMI_ERR_INVALID_ARG);
+    c.y_norm = pf; c.post_norm = 0;
+    expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(y_norm without post_norm)", LTXMI_ERR_INVALID_ARG);
+    // workspace (0.5): the plan of the decoder's 1024-channel stage (13 x 16 x 24 positions): three channel ranges; with the
+    // workspace the norm is available at that width, without it (or with too little of it) the call is the 0.4 one
+    memset(&c, 0, sizeof c);
+    c.x = p; c.w = p; c.bias = p; c.y = p;
+    c.B = 1; c.T = 13; c.H = 16; c.W = 24; c.Cin = 1024; c.Cout = 1024; c.causal = 1; c.pad_replicate = 1;
+    const int64_t want = ltxmi_conv3d_workspace_bytes(&c);
+    if (want != 3ll * 13 * 16 * 24 * 1024 * 4) { fprintf(stderr, "FAIL workspace_bytes(1024 -> 1024 at 13x16x24) = %lld\n", (long long)want); ++g_bad; }
+    if (ltxmi_conv3d_workspace_bytes(nullptr) != 0) { fprintf(stderr, "FAIL workspace_bytes(NULL)\n"); ++g_bad; }
+    c.post_norm = 1; c.post_eps = 1e-8f;
+    if (ltxmi_conv3d_fuses_post_norm(&c) != 0) { fprintf(stderr, "FAIL fuses_post_norm(Cout 1024, no workspace)\n"); ++g_bad; }
+    c.workspace = pf; c.workspace_bytes = want;
+    if (ltxmi_conv3d_fuses_post_norm(&c) != 1) { fprintf(stderr, "FAIL fuses_post_norm(Cout 1024, workspace)\n"); ++g_bad; }
+    expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(split + post_norm, no device)");
+    c.workspace_bytes = want - 4;
+    if (ltxmi_conv3d_fuses_post_norm(&c) != 0) { fprintf(stderr, "FAIL fuses_post_norm(workspace too small)\n"); ++g_bad; }
+    c.workspace = nullptr; c.workspace_bytes = want;
+    expect_fail(ltxmi_conv3d_ndhwc_bf16(&c, nullptr), "conv3d(workspace_bytes without a workspace)", LTXMI_ERR_INVALID_ARG);
+    c.workspace_bytes = 0; c.post_norm = 0; c.Cin = 512; c.Cout = 512; c.T = 25; c.H = 32; c.W = 48;
+    if (ltxmi_conv3d_workspace_bytes(&c) != 0) { fprintf(stderr, "FAIL workspace_bytes(512 -> 512 without a norm)\n"); ++g_bad; }
+    c.post_norm = 1;
+    if (ltxmi_conv3d_workspace_bytes(&c) != 2ll * 25 * 32 * 48 * 512 * 4) { fprintf(stderr, "FAIL workspace_bytes(512 -> 512 with a norm)\n"); ++g_bad; }
+    c.algo = 4;
+    if (ltxmi_conv3d_workspace_bytes(&c) != 0) { fprintf(stderr, "FAIL workspace_bytes(eight-wave form asked for)\n"); ++g_bad; }
 
     // ---- VAE pointwise / layout kernels, guidance, conditioning, upsampler
     expect_fail(ltxmi_pixelnorm_ada_silu_bf16(nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0.f, nullptr), "pixelnorm(NULL)");
